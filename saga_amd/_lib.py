@@ -1,0 +1,102 @@
+"""ctypes binding of ``libsaga_hip.so`` (declared in ``include/saga_hip.h``).
+
+The library is the only compute path of this package: if it is missing, or the tensors are
+not on a ROCm device, the ops raise -- there is no CPU or eager-PyTorch fallback.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libsaga_hip.so')
+
+c_float_p = ctypes.c_void_p
+c_int_p = ctypes.c_void_p
+c_stream = ctypes.c_void_p
+
+NUM_JOINTS = 55
+FEAT_K = 512
+N_ALIGN = 128
+BWD_SPLITK = 16
+DA_STRIDE = 840
+
+
+class ModelDesc(ctypes.Structure):
+    _fields_ = [
+        ('n_verts', ctypes.c_int32), ('n_shape', ctypes.c_int32), ('n_faces', ctypes.c_int32),
+        ('n_landmarks', ctypes.c_int32), ('n_extra_joints', ctypes.c_int32),
+        ('v_template_host', ctypes.c_void_p), ('shapedirs_host', ctypes.c_void_p),
+        ('posedirs_host', ctypes.c_void_p), ('J_regressor_host', ctypes.c_void_p),
+        ('parents_host', ctypes.c_void_p), ('lbs_weights_host', ctypes.c_void_p),
+        ('faces_host', ctypes.c_void_p), ('lmk_faces_idx_host', ctypes.c_void_p),
+        ('lmk_bary_host', ctypes.c_void_p), ('extra_joint_verts_host', ctypes.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/saga_hip.h declares
+PROTOTYPES = {
+    'saga_last_error': (ctypes.c_char_p, []),
+    'saga_version': (ctypes.c_int, []),
+    'saga_model_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ModelDesc)]),
+    'saga_model_destroy': (None, [ctypes.c_void_p]),
+    'saga_model_npad': (ctypes.c_int, [ctypes.c_void_p]),
+    'saga_model_num_joints_out': (ctypes.c_int, [ctypes.c_void_p]),
+    'saga_model_weight_nnz': (ctypes.c_int, [ctypes.c_void_p]),
+    'saga_smplx_fwd': (ctypes.c_int, [ctypes.c_void_p] + [c_float_p] * 11 + [ctypes.c_int, c_stream]),
+    'saga_smplx_bwd': (ctypes.c_int, [ctypes.c_void_p] + [c_float_p] * 15 + [ctypes.c_int, c_stream]),
+    'saga_rodrigues_fwd': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, c_stream]),
+    'saga_rodrigues_bwd': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, ctypes.c_int, c_stream]),
+    'saga_chamfer_fwd': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_int_p, c_int_p,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    'saga_chamfer_bwd': (ctypes.c_int, [c_float_p, c_float_p, c_int_p, c_int_p, c_float_p, c_float_p,
+                                        c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    'saga_vertex_normals': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_int, c_stream]),
+    'saga_vertex_normals_subset': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_int_p, ctypes.c_int, c_float_p,
+                                                  ctypes.c_int, c_stream]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise a clear error when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'saga_amd: %s not found. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(or `make -C saga_amd/csrc`). There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().saga_last_error()
+        raise RuntimeError('%s failed (code %d): %s' % (what, rc, msg.decode() if msg else '?'))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('saga_amd ops run on the GPU only (got a %s tensor); there is no CPU fallback' % t.device)
+        if t.dtype not in (torch.float32, torch.int32):
+            raise TypeError('saga_amd ops take float32 / int32 tensors, got %s' % t.dtype)

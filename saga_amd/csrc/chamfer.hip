@@ -1,0 +1,137 @@
+// chamfer_distance.ChamferDistance(x, y) -> (dist1, dist2, idx1, idx2): brute-force bidirectional nearest neighbour.
+// Replaces the third-party CUDA extension called at utils/train_helper.py:57.
+//
+// Tiled scan: the "database" cloud is staged through LDS as float4 (x,y,z,-) tiles and read back with broadcast
+// ds_read_b128; each lane owns QPL query points in registers and keeps (best, index) per query with a strict '<',
+// candidates visited in index order, so the lowest index wins ties.  The squared distance is evaluated as
+// (dx*dx + dy*dy) + dz*dz with one rounding per operation (contraction off) -- the order the CPU oracle uses --
+// so indices are bit-exact against it.  FP32 VALU bound.
+#include <math.h>
+
+#include "saga_common.h"
+
+#define NN_THREADS 256
+#define NN_TILE 1024
+
+template <int QPL>
+__global__ __launch_bounds__(NN_THREADS) void nn_scan_kernel(const float* __restrict__ q, const float* __restrict__ db,
+                                                             float* __restrict__ dist, int32_t* __restrict__ idx, int Pq,
+                                                             int Pd) {
+#pragma clang fp contract(off)
+    __shared__ float4 sdb[NN_TILE];
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x * (NN_THREADS * QPL);
+    const float* qn = q + (size_t)n * Pq * 3;
+    const float* dn = db + (size_t)n * Pd * 3;
+
+    float qx[QPL], qy[QPL], qz[QPL], best[QPL];
+    int bi[QPL];
+#pragma unroll
+    for (int i = 0; i < QPL; ++i) {
+        const int p = min(q0 + tid + i * NN_THREADS, Pq - 1);
+        qx[i] = qn[p * 3]; qy[i] = qn[p * 3 + 1]; qz[i] = qn[p * 3 + 2];
+        best[i] = INFINITY;
+        bi[i] = 0;
+    }
+    for (int t0 = 0; t0 < Pd; t0 += NN_TILE) {
+        const int cnt = min(NN_TILE, Pd - t0);
+        __syncthreads();
+        for (int k = tid; k < cnt; k += NN_THREADS) {
+            const float* p = dn + (size_t)(t0 + k) * 3;
+            sdb[k] = make_float4(p[0], p[1], p[2], 0.f);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < cnt; ++k) {
+            const float4 p = sdb[k];
+#pragma unroll
+            for (int i = 0; i < QPL; ++i) {
+                const float dx = qx[i] - p.x, dy = qy[i] - p.y, dz = qz[i] - p.z;
+                const float d = (dx * dx + dy * dy) + dz * dz;
+                const bool lt = d < best[i];
+                best[i] = lt ? d : best[i];
+                bi[i] = lt ? (t0 + k) : bi[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < QPL; ++i) {
+        const int p = q0 + tid + i * NN_THREADS;
+        if (p < Pq) {
+            if (dist) dist[(size_t)n * Pq + p] = best[i];
+            if (idx) idx[(size_t)n * Pq + p] = bi[i];
+        }
+    }
+}
+
+static int launch_scan(const float* q, const float* db, float* dist, int32_t* idx, int N, int Pq, int Pd, hipStream_t st) {
+    if (!dist && !idx) return 0;
+    if (Pq > NN_THREADS * 2) {
+        dim3 grid((Pq + NN_THREADS * 4 - 1) / (NN_THREADS * 4), N);
+        nn_scan_kernel<4><<<grid, NN_THREADS, 0, st>>>(q, db, dist, idx, Pq, Pd);
+    } else if (Pq > NN_THREADS) {
+        dim3 grid((Pq + NN_THREADS * 2 - 1) / (NN_THREADS * 2), N);
+        nn_scan_kernel<2><<<grid, NN_THREADS, 0, st>>>(q, db, dist, idx, Pq, Pd);
+    } else {
+        dim3 grid(1, N);
+        nn_scan_kernel<1><<<grid, NN_THREADS, 0, st>>>(q, db, dist, idx, Pq, Pd);
+    }
+    SAGA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int saga_chamfer_fwd(const float* x, const float* y, float* dist1, float* dist2, int32_t* idx1, int32_t* idx2,
+                                int N, int P1, int P2, void* stream) {
+    SAGA_CHECK_ARG(N >= 0 && P1 >= 0 && P2 >= 0, "saga_chamfer_fwd: negative size");
+    if (N == 0 || (P1 == 0 && P2 == 0)) return 0;
+    SAGA_CHECK_ARG(P1 > 0 && P2 > 0, "saga_chamfer_fwd: empty cloud (P1=%d, P2=%d) has no nearest neighbour", P1, P2);
+    SAGA_CHECK_ARG(x && y, "saga_chamfer_fwd: null cloud");
+    SAGA_CHECK_ARG(N <= 65535, "saga_chamfer_fwd: batch %d exceeds 65535", N);
+    int rc = launch_scan(x, y, dist1, idx1, N, P1, P2, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_scan(y, x, dist2, idx2, N, P2, P1, (hipStream_t)stream);
+}
+
+// Backward of the two squared-distance outputs (the extension's NmDistanceGrad): for every point p of a with
+// neighbour k in b: g = 2 * g_dist[p] * (a_p - b_k); g_a[p] += g; g_b[k] -= g.  Many p share one k -> atomics.
+__global__ void nn_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, const int32_t* __restrict__ idx,
+                               const float* __restrict__ g_dist, float* __restrict__ g_a, float* __restrict__ g_b, int N,
+                               int Pa, int Pb) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * Pa) return;
+    const int n = (int)(i / Pa);
+    const int k = idx[i];
+    const float g = 2.0f * g_dist[i];
+    const float* ap = a + i * 3;
+    const float* bp = b + ((size_t)n * Pb + k) * 3;
+    float* ga = g_a + i * 3;
+    float* gb = g_b + ((size_t)n * Pb + k) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = g * (ap[c] - bp[c]);
+        atomicAdd(ga + c, v);
+        atomicAdd(gb + c, -v);
+    }
+}
+
+extern "C" int saga_chamfer_bwd(const float* x, const float* y, const int32_t* idx1, const int32_t* idx2, const float* g_dist1,
+                                const float* g_dist2, float* g_x, float* g_y, int N, int P1, int P2, void* stream) {
+    SAGA_CHECK_ARG(N >= 0 && P1 >= 0 && P2 >= 0, "saga_chamfer_bwd: negative size");
+    if (N == 0 || P1 == 0 || P2 == 0) return 0;
+    SAGA_CHECK_ARG(x && y && g_x && g_y, "saga_chamfer_bwd: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (g_dist1) {
+        SAGA_CHECK_ARG(idx1, "saga_chamfer_bwd: idx1 missing");
+        const size_t tot = (size_t)N * P1;
+        nn_grad_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(x, y, idx1, g_dist1, g_x, g_y, N, P1, P2);
+        SAGA_LAUNCH_CHECK();
+    }
+    if (g_dist2) {
+        SAGA_CHECK_ARG(idx2, "saga_chamfer_bwd: idx2 missing");
+        const size_t tot = (size_t)N * P2;
+        nn_grad_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(y, x, idx2, g_dist2, g_y, g_x, N, P2, P1);
+        SAGA_LAUNCH_CHECK();
+    }
+    return 0;
+}

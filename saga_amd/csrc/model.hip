@@ -1,0 +1,178 @@
+// Model constants: host-side re-layout + upload.  Replaces the buffers smplx.create() registers
+// (reference call site WholeGraspPose/models/fittingop.py:30-59).
+#include <stdarg.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "saga_common.h"
+
+static thread_local char g_err[512] = "";
+
+void saga_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* saga_last_error(void) { return g_err; }
+extern "C" int saga_version(void) { return 100; }
+
+template <typename T>
+static int upload(T** dst, const std::vector<T>& src) {
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    SAGA_HIP(hipMalloc((void**)dst, bytes));
+    if (!src.empty()) SAGA_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" void saga_model_destroy(saga_model_t* m) {
+    if (!m) return;
+    void* ptrs[] = {m->Bt, m->Bk, m->v_template, m->J_template, m->J_dirs, m->parents, m->depth, m->child_ptr,
+                    m->child_idx, m->w_idx, m->w_val, m->Wd, m->faces, m->vf_ptr, m->vf_idx, m->lmk_verts,
+                    m->lmk_bary, m->extra_verts};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete m;
+}
+
+extern "C" int saga_model_npad(const saga_model_t* m) { return m ? m->Npad : SAGA_EINVAL; }
+extern "C" int saga_model_num_joints_out(const saga_model_t* m) { return m ? NJ + m->E + m->L : SAGA_EINVAL; }
+extern "C" int saga_model_weight_nnz(const saga_model_t* m) { return m ? m->KW : SAGA_EINVAL; }
+
+extern "C" int saga_model_create(saga_model_t** out, const saga_model_desc_t* d) {
+    SAGA_CHECK_ARG(out && d, "saga_model_create: null argument");
+    *out = nullptr;
+    const int V = d->n_verts, S = d->n_shape, F = d->n_faces, L = d->n_landmarks, E = d->n_extra_joints;
+    SAGA_CHECK_ARG(V > 0 && F >= 0 && L >= 0 && E >= 0, "saga_model_create: bad sizes V=%d F=%d L=%d E=%d", V, F, L, E);
+    SAGA_CHECK_ARG(S >= 0 && S + NPF <= FEAT_K, "saga_model_create: n_shape=%d does not fit K=%d", S, FEAT_K);
+    SAGA_CHECK_ARG(d->v_template_host && d->posedirs_host && d->J_regressor_host && d->parents_host &&
+                       d->lbs_weights_host && (S == 0 || d->shapedirs_host),
+                   "saga_model_create: null array");
+    SAGA_CHECK_ARG(F == 0 || d->faces_host, "saga_model_create: faces missing");
+    SAGA_CHECK_ARG(L == 0 || (d->lmk_faces_idx_host && d->lmk_bary_host && F > 0), "saga_model_create: landmarks missing");
+    SAGA_CHECK_ARG(E == 0 || d->extra_joint_verts_host, "saga_model_create: extra joints missing");
+    SAGA_CHECK_ARG(d->parents_host[0] == -1, "saga_model_create: parents[0] must be -1");
+    for (int j = 1; j < NJ; ++j)
+        SAGA_CHECK_ARG(d->parents_host[j] >= 0 && d->parents_host[j] < j, "saga_model_create: parents[%d]=%d not topological", j,
+                       d->parents_host[j]);
+    for (int f = 0; f < 3 * F; ++f)
+        SAGA_CHECK_ARG(d->faces_host[f] >= 0 && d->faces_host[f] < V, "saga_model_create: face index out of range");
+    for (int l = 0; l < L; ++l)
+        SAGA_CHECK_ARG(d->lmk_faces_idx_host[l] >= 0 && d->lmk_faces_idx_host[l] < F, "saga_model_create: landmark face out of range");
+    for (int e = 0; e < E; ++e)
+        SAGA_CHECK_ARG(d->extra_joint_verts_host[e] >= 0 && d->extra_joint_verts_host[e] < V,
+                       "saga_model_create: extra joint vertex %d out of range", d->extra_joint_verts_host[e]);
+
+    hipDeviceProp_t prop;
+    int dev = 0;
+    SAGA_HIP(hipGetDevice(&dev));
+    SAGA_HIP(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        saga_set_error("libsaga_hip is built for gfx950 only; device %d is %s", dev, prop.gcnArchName);
+        return SAGA_EDEVICE;
+    }
+
+    saga_model* m = new saga_model();
+    memset(m, 0, sizeof(*m));
+    m->V = V; m->S = S; m->F = F; m->L = L; m->E = E;
+    m->N = 3 * V;
+    m->Npad = saga_roundup(3 * V, SAGA_N_ALIGN);
+    m->Vpad4 = saga_roundup(V, 256);
+    m->device = dev;
+    const int N = m->N, Npad = m->Npad;
+    int rc = 0;
+
+    {   // blend operands, both orientations
+        std::vector<float> Bt((size_t)Npad * FEAT_K, 0.f), Bk((size_t)FEAT_K * Npad, 0.f), vt(Npad, 0.f);
+        for (int n = 0; n < N; ++n) {
+            float* row = &Bt[(size_t)n * FEAT_K];
+            for (int s = 0; s < S; ++s) row[s] = d->shapedirs_host[(size_t)n * S + s];
+            for (int p = 0; p < NPF; ++p) row[S + p] = d->posedirs_host[(size_t)p * N + n];
+            vt[n] = d->v_template_host[n];
+        }
+        for (int k = 0; k < FEAT_K; ++k)
+            for (int n = 0; n < N; ++n) Bk[(size_t)k * Npad + n] = Bt[(size_t)n * FEAT_K + k];
+        if ((rc = upload(&m->Bt, Bt)) || (rc = upload(&m->Bk, Bk)) || (rc = upload(&m->v_template, vt))) goto fail;
+    }
+    {   // folded joint regression (accumulated in double)
+        std::vector<float> Jt(NJ * 3), Jd((size_t)std::max(S, 1) * NJ * 3, 0.f);
+        for (int j = 0; j < NJ; ++j) {
+            const float* reg = d->J_regressor_host + (size_t)j * V;
+            double acc[3] = {0, 0, 0};
+            std::vector<double> accd((size_t)3 * S, 0.0);
+            for (int v = 0; v < V; ++v) {
+                double w = reg[v];
+                if (w == 0.0) continue;
+                for (int c = 0; c < 3; ++c) {
+                    acc[c] += w * d->v_template_host[v * 3 + c];
+                    for (int s = 0; s < S; ++s) accd[c * S + s] += w * d->shapedirs_host[((size_t)v * 3 + c) * S + s];
+                }
+            }
+            for (int c = 0; c < 3; ++c) {
+                Jt[j * 3 + c] = (float)acc[c];
+                for (int s = 0; s < S; ++s) Jd[(size_t)s * NJ * 3 + j * 3 + c] = (float)accd[c * S + s];
+            }
+        }
+        if ((rc = upload(&m->J_template, Jt)) || (rc = upload(&m->J_dirs, Jd))) goto fail;
+    }
+    {   // kinematic tree
+        std::vector<int32_t> par(d->parents_host, d->parents_host + NJ), depth(NJ, 0), cptr(NJ + 1, 0), cidx;
+        for (int j = 1; j < NJ; ++j) depth[j] = depth[par[j]] + 1;
+        m->max_depth = *std::max_element(depth.begin(), depth.end());
+        for (int p = 0; p < NJ; ++p) {
+            cptr[p] = (int32_t)cidx.size();
+            for (int j = 1; j < NJ; ++j)
+                if (par[j] == p) cidx.push_back(j);
+        }
+        cptr[NJ] = (int32_t)cidx.size();
+        memcpy(m->h_parents, par.data(), sizeof(int32_t) * NJ);
+        if ((rc = upload(&m->parents, par)) || (rc = upload(&m->depth, depth)) || (rc = upload(&m->child_ptr, cptr)) ||
+            (rc = upload(&m->child_idx, cidx)))
+            goto fail;
+    }
+    {   // skinning weights
+        int KW = 1;
+        for (int v = 0; v < V; ++v) {
+            int nnz = 0;
+            for (int j = 0; j < NJ; ++j) nnz += d->lbs_weights_host[(size_t)v * NJ + j] != 0.f;
+            KW = std::max(KW, nnz);
+        }
+        KW = saga_roundup(KW, 2);
+        m->KW = KW;
+        std::vector<int32_t> wi((size_t)V * KW, 0);
+        std::vector<float> wv((size_t)V * KW, 0.f), Wd((size_t)m->Vpad4 * WT_COLS, 0.f);
+        for (int v = 0; v < V; ++v) {
+            int k = 0;
+            for (int j = 0; j < NJ; ++j) {
+                float w = d->lbs_weights_host[(size_t)v * NJ + j];
+                Wd[(size_t)v * WT_COLS + j] = w;
+                if (w != 0.f) { wi[(size_t)v * KW + k] = j; wv[(size_t)v * KW + k] = w; ++k; }
+            }
+            Wd[(size_t)v * WT_COLS + NJ] = 1.f;
+        }
+        if ((rc = upload(&m->w_idx, wi)) || (rc = upload(&m->w_val, wv)) || (rc = upload(&m->Wd, Wd))) goto fail;
+    }
+    {   // faces, vertex->face incidence (ascending face order), landmarks, extra joints
+        std::vector<int32_t> faces(d->faces_host, d->faces_host + (size_t)3 * F), vptr(V + 1, 0), vidx((size_t)3 * F);
+        for (int f = 0; f < 3 * F; ++f) vptr[faces[f] + 1]++;
+        for (int v = 0; v < V; ++v) vptr[v + 1] += vptr[v];
+        std::vector<int32_t> fill(vptr.begin(), vptr.end() - 1);
+        for (int f = 0; f < F; ++f)
+            for (int c = 0; c < 3; ++c) vidx[fill[faces[f * 3 + c]]++] = f;
+        std::vector<int32_t> lv((size_t)3 * L);
+        std::vector<float> lb(d->lmk_bary_host, d->lmk_bary_host + (size_t)3 * L);
+        for (int l = 0; l < L; ++l)
+            for (int c = 0; c < 3; ++c) lv[l * 3 + c] = faces[d->lmk_faces_idx_host[l] * 3 + c];
+        std::vector<int32_t> ev(d->extra_joint_verts_host, d->extra_joint_verts_host + E);
+        if ((rc = upload(&m->faces, faces)) || (rc = upload(&m->vf_ptr, vptr)) || (rc = upload(&m->vf_idx, vidx)) ||
+            (rc = upload(&m->lmk_verts, lv)) || (rc = upload(&m->lmk_bary, lb)) || (rc = upload(&m->extra_verts, ev)))
+            goto fail;
+    }
+    *out = m;
+    return 0;
+fail:
+    saga_model_destroy(m);
+    return rc;
+}

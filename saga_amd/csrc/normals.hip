@@ -1,0 +1,59 @@
+// Area-weighted vertex normals.  Replaces Open3D TriangleMesh.compute_vertex_normals() as called every
+// iteration at WholeGraspPose/models/fittingop.py:158-164 (a device->host->device round trip in the reference).
+// Gather formulation: each output vertex walks its incident faces in ascending face order (the order Open3D's
+// face loop adds them), sums the un-normalised cross products and normalises; zero rows stay zero, NaN -> (0,0,1).
+// No atomics, deterministic.  HBM/L2-bound gather.
+#include <math.h>
+
+#include "saga_common.h"
+
+__global__ void vertex_normals_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces,
+                                      const int32_t* __restrict__ vf_ptr, const int32_t* __restrict__ vf_idx,
+                                      const int32_t* __restrict__ sel, int n_out, float* __restrict__ normals, int V) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (o >= n_out) return;
+    const int v = sel ? sel[o] : o;
+    const float* vb = verts + (size_t)b * V * 3;
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    const int e0 = vf_ptr[v], e1 = vf_ptr[v + 1];
+    for (int e = e0; e < e1; ++e) {
+        const int f = vf_idx[e];
+        const int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
+        const float ax = vb[i1 * 3] - vb[i0 * 3], ay = vb[i1 * 3 + 1] - vb[i0 * 3 + 1], az = vb[i1 * 3 + 2] - vb[i0 * 3 + 2];
+        const float bx = vb[i2 * 3] - vb[i0 * 3], by = vb[i2 * 3 + 1] - vb[i0 * 3 + 1], bz = vb[i2 * 3 + 2] - vb[i0 * 3 + 2];
+        nx += ay * bz - az * by;
+        ny += az * bx - ax * bz;
+        nz += ax * by - ay * bx;
+    }
+    const float sq = nx * nx + ny * ny + nz * nz;
+    if (sq > 0.f) {
+        const float inv = 1.0f / sqrtf(sq);
+        nx *= inv; ny *= inv; nz *= inv;
+    }
+    if (isnan(nx)) { nx = 0.f; ny = 0.f; nz = 1.f; }
+    float* out = normals + ((size_t)b * n_out + o) * 3;
+    out[0] = nx; out[1] = ny; out[2] = nz;
+}
+
+static int launch(const saga_model_t* m, const float* verts, const int32_t* sel, int n_out, float* normals, int B, void* stream) {
+    SAGA_CHECK_ARG(m && m->F > 0, "saga_vertex_normals: model has no faces");
+    SAGA_CHECK_ARG(B >= 0 && B <= 65535 && n_out >= 0, "saga_vertex_normals: bad sizes B=%d n=%d", B, n_out);
+    if (B == 0 || n_out == 0) return 0;
+    SAGA_CHECK_ARG(verts && normals, "saga_vertex_normals: null argument");
+    dim3 grid((n_out + 255) / 256, B);
+    vertex_normals_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(verts, m->faces, m->vf_ptr, m->vf_idx, sel, n_out, normals, m->V);
+    SAGA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int saga_vertex_normals(const saga_model_t* m, const float* verts, float* normals, int B, void* stream) {
+    return launch(m, verts, nullptr, m ? m->V : 0, normals, B, stream);
+}
+
+// `sel` (device, int32) must hold vertex ids in [0, V): checked by the host wrapper that uploads it.
+extern "C" int saga_vertex_normals_subset(const saga_model_t* m, const float* verts, const int32_t* sel, int n_sel, float* normals,
+                                          int B, void* stream) {
+    SAGA_CHECK_ARG(sel || n_sel == 0, "saga_vertex_normals_subset: null selection");
+    return launch(m, verts, sel, n_sel, normals, B, stream);
+}

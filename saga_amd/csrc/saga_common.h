@@ -1,0 +1,79 @@
+// Internal definitions shared by the HIP translation units of libsaga_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/saga_hip.h"
+
+#define NJ SAGA_NUM_JOINTS      // 55
+#define NPF 486                 // pose-feature length (54 joints x 9)
+#define FEAT_K SAGA_FEAT_K      // 512
+#define DA_ROWS 56              // 55 joints + 1 all-ones row (sum of gradients -> d transl)
+#define WT_COLS 64              // dense weight table padded to 64 columns for the MFMA dA reduction
+
+void saga_set_error(const char* fmt, ...);
+
+#define SAGA_CHECK_ARG(cond, ...)                      \
+    do {                                               \
+        if (!(cond)) {                                 \
+            saga_set_error(__VA_ARGS__);               \
+            return SAGA_EINVAL;                        \
+        }                                              \
+    } while (0)
+
+#define SAGA_HIP(call)                                                              \
+    do {                                                                            \
+        hipError_t e_ = (call);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            saga_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (int)e_;                                                         \
+        }                                                                           \
+    } while (0)
+
+#define SAGA_LAUNCH_CHECK()                                                         \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) {                                                     \
+            saga_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (int)e_;                                                         \
+        }                                                                           \
+    } while (0)
+
+// Device-resident model constants, laid out for the kernels (see DESIGN.md 'Data layout in HBM').
+struct saga_model {
+    int V, S, F, L, E;
+    int N;        // 3V
+    int Npad;     // roundup(3V, 128)
+    int KW;       // entries per vertex in the compressed weight table
+    int max_depth;
+    int device;
+    // blend contraction operands
+    float* Bt;          // [Npad, 512]  Bt[n][k]: k<S shapedirs, S<=k<S+486 posedirs, else 0 (forward B operand)
+    float* Bk;          // [512, Npad]  the transpose (backward B operand)
+    float* v_template;  // [Npad] (pad = 0)
+    // folded joint regression: J = J_template + shape . J_dirs
+    float* J_template;  // [55*3]
+    float* J_dirs;      // [S, 165]
+    // kinematic tree
+    int32_t* parents;   // [55]
+    int32_t* depth;     // [55]
+    int32_t* child_ptr; // [56] CSR of children
+    int32_t* child_idx; // [54]
+    int32_t h_parents[NJ];
+    // skinning weights: compressed rows (joint, weight) and dense padded table for the dA reduction
+    int32_t* w_idx;     // [V, KW]
+    float*   w_val;     // [V, KW] (pad entries: idx 0, weight 0)
+    float*   Wd;        // [Vpad4, 64]  Wd[v][j] = W[v][j] (j<55), 1 (j=55), 0 (j>55); rows >= V are 0
+    int Vpad4;          // roundup(V, 256)
+    // faces / landmarks / extra joints
+    int32_t* faces;     // [F,3]
+    int32_t* vf_ptr;    // [V+1] CSR vertex -> incident (face, corner) in ascending face order
+    int32_t* vf_idx;    // [3F]  face id
+    int32_t* lmk_verts; // [L,3] vertex ids of each landmark's triangle
+    float*   lmk_bary;  // [L,3]
+    int32_t* extra_verts; // [E]
+};
+
+static inline int saga_roundup(int x, int m) { return (x + m - 1) / m * m; }

@@ -1,0 +1,78 @@
+// extern "C" orchestration of the SMPL-X forward / backward (kernel sequence on one stream, no allocation, no sync).
+#include "saga_common.h"
+
+int saga_launch_pose_fwd(const saga_model* m, const float* shape, const float* full_pose, float* feat, float* rot,
+                         float* jrest, float* chain, float* A, int B, hipStream_t st);
+int saga_launch_pose_bwd(const saga_model* m, const float* dA, const float* g_pj, const float* g_jsum, const float* slabs,
+                         int n_slabs, const float* rot, const float* jrest, const float* chain, const float* full_pose,
+                         float* g_shape, float* g_full_pose, float* g_transl, int B, int has_verts, hipStream_t st);
+int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed, int B, hipStream_t st);
+int saga_launch_blend_bwd(const saga_model* m, const float* g_vposed, float* slabs, int B, hipStream_t st);
+int saga_launch_skin_fwd(const saga_model* m, const float* A, const float* v_posed, const float* transl, float* verts, int B,
+                         hipStream_t st);
+int saga_launch_joints_fwd(const saga_model* m, const float* chain, const float* verts, const float* transl, float* joints, int B,
+                           hipStream_t st);
+int saga_launch_joints_bwd(const saga_model* m, const float* g_joints, float* g_pj, float* g_jsum, float* gv, int B,
+                           int small_stride, hipStream_t st);
+int saga_launch_skin_bwd(const saga_model* m, const float* A, const float* g_verts, const float* v_posed, float* g_vposed,
+                         float* dA, int dA_stride, int B, hipStream_t st);
+
+extern "C" int saga_smplx_fwd(const saga_model_t* m, const float* shape, const float* full_pose, const float* transl,
+                              float* vertices, float* joints, float* feat, float* rot, float* jrest, float* chain, float* A,
+                              float* v_posed, int B, void* stream) {
+    SAGA_CHECK_ARG(m, "saga_smplx_fwd: null model");
+    SAGA_CHECK_ARG(B >= 0 && B <= 65535, "saga_smplx_fwd: batch %d outside [0, 65535]", B);
+    if (B == 0) return 0;
+    SAGA_CHECK_ARG(full_pose && vertices && feat && rot && jrest && chain && A && v_posed && (m->S == 0 || shape),
+                   "saga_smplx_fwd: null buffer");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = saga_launch_pose_fwd(m, shape, full_pose, feat, rot, jrest, chain, A, B, st))) return rc;
+    if ((rc = saga_launch_blend_fwd(m, feat, v_posed, B, st))) return rc;
+    if ((rc = saga_launch_skin_fwd(m, A, v_posed, transl, vertices, B, st))) return rc;
+    if (joints && (rc = saga_launch_joints_fwd(m, chain, vertices, transl, joints, B, st))) return rc;
+    return 0;
+}
+
+extern "C" int saga_smplx_bwd(const saga_model_t* m, const float* g_vertices, const float* g_joints, const float* full_pose,
+                              const float* rot, const float* jrest, const float* chain, const float* A, const float* v_posed,
+                              float* g_shape, float* g_full_pose, float* g_transl, float* ws_gvp, float* ws_slab, float* ws_dA,
+                              float* ws_gv, int B, void* stream) {
+    SAGA_CHECK_ARG(m, "saga_smplx_bwd: null model");
+    SAGA_CHECK_ARG(B >= 0 && B <= 65535, "saga_smplx_bwd: batch %d outside [0, 65535]", B);
+    if (B == 0) return 0;
+    SAGA_CHECK_ARG(g_vertices || g_joints, "saga_smplx_bwd: no incoming gradient");
+    SAGA_CHECK_ARG(full_pose && rot && jrest && chain && A && v_posed && g_full_pose && g_transl && ws_dA && (m->S == 0 || g_shape),
+                   "saga_smplx_bwd: null buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const int V = m->V;
+    const int stride = SAGA_DA_STRIDE;
+    float* g_pj = nullptr;
+    float* g_jsum = nullptr;
+    const float* gv = g_vertices;
+    int has_verts = g_vertices != nullptr;
+    int rc;
+    if (g_joints) {
+        // extra joints and landmarks are functions of the vertices: fold their gradient into a private copy
+        const bool touches_verts = (m->E + m->L) > 0;
+        g_pj = ws_dA + DA_ROWS * 12;
+        g_jsum = g_pj + NJ * 3;
+        if (touches_verts) {
+            SAGA_CHECK_ARG(ws_gv, "saga_smplx_bwd: ws_gv is required when g_joints is given");
+            if (g_vertices)
+                SAGA_HIP(hipMemcpyAsync(ws_gv, g_vertices, (size_t)B * V * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            else
+                SAGA_HIP(hipMemsetAsync(ws_gv, 0, (size_t)B * V * 3 * sizeof(float), st));
+            gv = ws_gv;
+            has_verts = 1;
+        }
+        if ((rc = saga_launch_joints_bwd(m, g_joints, g_pj, g_jsum, ws_gv, B, stride, st))) return rc;
+    }
+    if (has_verts) {
+        SAGA_CHECK_ARG(ws_gvp && ws_slab, "saga_smplx_bwd: workspace missing");
+        if ((rc = saga_launch_skin_bwd(m, A, gv, v_posed, ws_gvp, ws_dA, stride, B, st))) return rc;
+        if ((rc = saga_launch_blend_bwd(m, ws_gvp, ws_slab, B, st))) return rc;
+    }
+    return saga_launch_pose_bwd(m, ws_dA, g_pj, g_jsum, ws_slab, SAGA_BWD_SPLITK, rot, jrest, chain, full_pose, g_shape, g_full_pose,
+                                g_transl, B, has_verts, st);
+}

@@ -1,0 +1,269 @@
+"""Batched GraspPose-Opt: the counterpart of ``WholeGraspPose/models/fittingop.py`` (``FittingOP``)
+and of the per-sample loop in ``opt_grasppose.py:164-243``.
+
+The reference fits ONE candidate at a time (``batch_size=1``, serial Python loops
+``opt_grasppose.py:211,220``).  Here B candidates are fitted at once as B independent problems:
+every mean in the loss is per candidate, the objective handed to ``backward`` is the sum over
+candidates, and Adam is element-wise -- so each candidate follows the update sequence it would
+follow alone.  The per-iteration arithmetic (SMPL-X forward/backward, vertex normals, the two
+bidirectional nearest-neighbour searches) runs in ``libsaga_hip.so``; nothing is copied to the host
+inside the loop (the reference crosses device->host->device for normals, ``fittingop.py:158-164``, and
+pulls 14 scalars per iteration, ``:225-242``).
+"""
+import os
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from . import smplx as _smplx
+from .geometry import point2point_signed, vertex_normals_subset
+from .rotations import RotConverter
+from .vposer import VPoserDecoder
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'grasp_indices.npz')
+
+LOSS_KEYS = ['total', 'rec', 'body_rec', 'marker contact', 'object contact', 'prior contact',
+             'hand collision', 'object collision', 'foot', 'reg']
+COUNT_KEYS = ['hand colli', 'obj colli', 'contact', 'hand markers colli']
+PARAM_KEYS = ['transl', 'global_orient', 'betas', 'body_pose', 'left_hand_pose', 'right_hand_pose', 'leye_pose', 'reye_pose']
+
+
+def load_grasp_indices(path=None):
+    """markers_143 / rhand / foot vertex ids and rhand_weight (``fittingop.py:86-124``).
+
+    The packaged ``data/grasp_indices.npz`` was derived from the reference's ``body_utils`` files with
+    the reference's own expressions (``tests/golden/make_golden.py``), including the CPython-``set``
+    ordering that selects the 172 foot vertices."""
+    d = np.load(path or _DATA, allow_pickle=False)
+    return {k: d[k] for k in ('markers_143', 'rhand', 'lhand', 'foot', 'rhand_weight')}
+
+
+class FittingOP:
+    """Same constructor contract as the reference (``FittingOP(fittingconfig)``, keys as at
+    ``opt_grasppose.py:179-191``) plus optional keys: ``body_model_path`` (default
+    ``./body_utils/body_models``), ``vposer`` (a module with ``decode(z, output_type='aa')``; default: a
+    random-initialised :class:`VPoserDecoder`), ``indices`` (dict from :func:`load_grasp_indices`),
+    ``smplx_kwargs`` (extra ``smplx.create`` kwargs, e.g. ``vertex_ids`` for reduced test meshes),
+    ``genders`` (which models to create; default both like the reference)."""
+
+    def __init__(self, fittingconfig):
+        cfg = dict(init_lr_h=0.008, num_iter=[300, 400, 500], batch_size=1, num_markers=143, device='cuda',
+                   verbose=False, hand_ncomps=24, only_rec=False, contact_loss='contact', logger=print,
+                   data_type='markers_143', body_model_path='./body_utils/body_models', vposer=None, indices=None,
+                   smplx_kwargs={}, genders=('male', 'female'))
+        cfg.update(fittingconfig)
+        for key, val in cfg.items():
+            setattr(self, key, val)
+        self.device = torch.device(self.device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('saga_amd.FittingOP runs on a ROCm GPU only (device=%s)' % self.device)
+        B = self.batch_size
+
+        def make(gender):
+            bm = _smplx.create(self.body_model_path, model_type='smplx', gender=gender, ext='npz',
+                               num_pca_comps=self.hand_ncomps, create_global_orient=True, create_body_pose=True,
+                               create_betas=True, create_left_hand_pose=True, create_right_hand_pose=True,
+                               create_expression=True, create_jaw_pose=True, create_leye_pose=True,
+                               create_reye_pose=True, create_transl=True, batch_size=B, **self.smplx_kwargs)
+            return bm.to(self.device).eval()
+
+        self.bm_male = make('male') if 'male' in self.genders else None
+        self.bm_female = make('female') if 'female' in self.genders else None
+        self.bm = None
+        if self.vposer is None:
+            self.vposer = VPoserDecoder(seed=0)
+        self.vposer = self.vposer.to(self.device).eval()
+        for p in self.vposer.parameters():
+            p.requires_grad_(False)
+        self.fittingconfig = fittingconfig
+
+        # optimisation variables (fittingop.py:71-76) and the three Adam optimisers (:77-84)
+        z = lambda n: torch.zeros(B, n, device=self.device, requires_grad=True)
+        self.betas = z(10)
+        self.transl_rec = z(3)
+        self.glo_rot_rec = torch.tensor([[-1., 0, 0, 0, 0, 1]], device=self.device).repeat(B, 1).requires_grad_(True)
+        self.vpose_rec = z(32)
+        self.hand_pose = z(2 * self.hand_ncomps)
+        self.eye_pose = z(6)
+        self._make_optimizers()
+
+        idx = self.indices if self.indices is not None else load_grasp_indices()
+        dev = self.device
+        self.v_weights = torch.as_tensor(np.asarray(idx['rhand_weight']), dtype=torch.float32, device=dev)
+        self.v_weights2 = torch.pow(self.v_weights, 1.0 / 2.5)
+        self.markers_143 = torch.as_tensor(np.asarray(idx['markers_143']), dtype=torch.long, device=dev)
+        self.rhand_verts = torch.as_tensor(np.asarray(idx['rhand']), dtype=torch.long, device=dev)
+        self.foot_markers_all = torch.as_tensor(np.asarray(idx['foot']), dtype=torch.long, device=dev)
+        self.rhand_verts_i32 = self.rhand_verts.to(torch.int32)
+
+    def _make_optimizers(self):
+        lr = self.init_lr_h
+        self.optimizer_s1 = optim.Adam([self.transl_rec, self.glo_rot_rec], lr=lr * 2.0)
+        self.optimizer_s2 = optim.Adam([self.betas, self.transl_rec, self.glo_rot_rec, self.vpose_rec], lr=lr * 1.5)
+        self.optimizer_s3 = optim.Adam([self.vpose_rec, self.hand_pose, self.eye_pose], lr=lr)
+        self.optimizers = [self.optimizer_s1, self.optimizer_s2, self.optimizer_s3]
+
+    def variables(self):
+        return {'betas': self.betas, 'transl_rec': self.transl_rec, 'glo_rot_rec': self.glo_rot_rec,
+                'vpose_rec': self.vpose_rec, 'hand_pose': self.hand_pose, 'eye_pose': self.eye_pose}
+
+    def set_variables(self, values):
+        with torch.no_grad():
+            for k, v in values.items():
+                getattr(self, k).copy_(torch.as_tensor(v, dtype=torch.float32, device=self.device))
+
+    def init_betas(self, betas):
+        with torch.no_grad():
+            self.betas.copy_(torch.as_tensor(betas, dtype=torch.float32, device=self.device).reshape(1, -1).expand_as(self.betas))
+
+    def reset(self):
+        """fittingop.py:129-135 (the reference keeps its Adam moments across samples; here a fresh batch gets
+        fresh optimisers, which is what a first call sees)."""
+        with torch.no_grad():
+            for t in (self.betas, self.transl_rec, self.vpose_rec, self.hand_pose, self.eye_pose):
+                t.zero_()
+            self.glo_rot_rec.copy_(torch.tensor([[-1., 0, 0, 0, 0, 1]], device=self.device).expand_as(self.glo_rot_rec))
+        self._make_optimizers()
+
+    # ------------------------------------------------------------------------------------------------
+    def body_params(self):
+        B, n = self.batch_size, self.hand_ncomps
+        return {
+            'transl': self.transl_rec,
+            'global_orient': RotConverter.rotmat2aa(RotConverter.cont2rotmat(self.glo_rot_rec)),
+            'betas': self.betas,
+            'body_pose': self.vposer.decode(self.vpose_rec, output_type='aa').view(B, -1),
+            'left_hand_pose': self.hand_pose[:, :n],
+            'right_hand_pose': self.hand_pose[:, n:],
+            'leye_pose': self.eye_pose[:, :3],
+            'reye_pose': self.eye_pose[:, 3:],
+        }
+
+    def calc_loss_contact_map(self, body_markers, verts_object, normal_object, contacts_object, contacts_markers,
+                              gender, betas, stage, alpha):
+        """fittingop.py:137-244 for B candidates.  ``loss`` and every ``loss_dict`` / ``vertices_info``
+        entry is a [B] device tensor (per-candidate values); call ``loss.sum().backward()``."""
+        B = self.batch_size
+        body_param = self.body_params()
+        output = self.bm(return_verts=True, **body_param)
+        verts_full = output.vertices
+        body_markers_rec = verts_full[:, self.markers_143, :]
+        foot_markers_rec = verts_full[:, self.foot_markers_all, :]
+        rhand_verts_rec = verts_full[:, self.rhand_verts, :]
+        # vertex normals of the right hand, on the device, for every candidate (:158-164)
+        rh_normals = vertex_normals_subset(self.bm, verts_full, self.rhand_verts_i32)
+
+        tgt = body_markers.detach()
+        loss_rec = (body_markers_rec - tgt).abs().mean(dim=(1, 2))
+        loss_body_rec = (body_markers_rec[:, :49] - tgt[:, :49]).abs().mean(dim=(1, 2))
+        loss_foot = 0.1 * foot_markers_rec[:, :, -1].abs().mean(dim=1)
+        loss_vpose_reg = 0.0001 * (self.vpose_rec ** 2).mean(dim=1)
+        loss_hand_pose_reg = 0.0005 * (self.hand_pose ** 2).mean(dim=1)
+        loss_eye_pose_reg = 0.0001 * (self.eye_pose ** 2).mean(dim=1)
+
+        vo, no = verts_object.float(), normal_object.float()
+        # :183 passes normal_object positionally as x_normals (kept: the signed output is unused)
+        o2h_marker, h2o_signed_marker, o2h_idx_marker, _ = point2point_signed(body_markers_rec, vo, no)
+        o2h_signed, h2o_signed, o2h_idx, _ = point2point_signed(rhand_verts_rec, vo, rh_normals, no)
+
+        loss_marker_contact = (h2o_signed_marker.abs() * contacts_markers.view(B, -1)).mean(dim=1)
+        loss_object_contact = (o2h_signed.abs() * contacts_object.view(B, -1)).mean(dim=1)
+        zero_h = torch.zeros_like(h2o_signed)
+        v_dist = (h2o_signed < 0.02) & (h2o_signed > 0) & (self.v_weights2[None] > 0.7)
+        v_dist_neg = h2o_signed < 0
+        v_dist_marker_neg = h2o_signed_marker < 0
+        v_contact = torch.where(v_dist, self.v_weights[None].expand_as(h2o_signed), zero_h)
+        v_collision = torch.where(v_dist_neg, torch.full_like(h2o_signed, 10.0), zero_h)
+        w_dist_neg = o2h_signed < 0
+        w = torch.where(w_dist_neg, torch.full_like(o2h_signed, 20.0), torch.zeros_like(o2h_signed))
+        loss_prior_contact = (h2o_signed.abs() * v_contact).mean(dim=1)
+        h_collision = (h2o_signed.abs() * v_collision).mean(dim=1)
+        loss_dist_o = (o2h_signed.abs() * w).mean(dim=1)
+
+        on = 0.0 if self.only_rec else 1.0
+        loss = (1 * loss_rec
+                + on * (self.contact_loss == 'contact') * (stage > 1) * 15 * (loss_marker_contact + loss_object_contact)
+                + on * (self.contact_loss == 'prior') * (stage > 1) * 15 * loss_prior_contact
+                + on * (stage > 1) * 10 * (h_collision + loss_dist_o)
+                + (stage > 1) * loss_hand_pose_reg
+                + (stage > 1) * loss_eye_pose_reg
+                + (stage > 0) * loss_vpose_reg
+                + 0.1 * loss_foot)
+
+        d = lambda t: t.detach()
+        loss_dict = {
+            'total': d(loss), 'rec': d(loss_rec), 'body_rec': d(loss_body_rec),
+            'marker contact': d(loss_marker_contact), 'object contact': d(loss_object_contact),
+            'prior contact': d(loss_prior_contact), 'hand collision': d(h_collision),
+            'object collision': d(loss_dist_o), 'foot': d(loss_foot),
+            'reg': d(loss_vpose_reg + loss_hand_pose_reg + loss_eye_pose_reg),
+        }
+        vertices_info = {
+            'hand colli': v_dist_neg.sum(dim=1), 'obj colli': w_dist_neg.sum(dim=1),
+            'contact': ((h2o_signed < 0.001) & (h2o_signed > -0.001)).sum(dim=1),
+            'hand markers colli': v_dist_marker_neg.sum(dim=1),
+        }
+        return loss, loss_dict, body_markers_rec, body_param, vertices_info, rhand_verts_rec, rh_normals, h2o_signed, o2h_signed
+
+    def _snapshot(self):
+        with torch.no_grad():
+            return {k: v.detach().clone() for k, v in self.body_params().items()}
+
+    def fitting(self, body_markers, object_contact, markers_contact, verts_object, normal_object, gender, betas=None,
+                log_every=0):
+        """fittingop.py:343-499 for a batch.  Returns ``(markers_fit_list, smplxparams_list, save_loss)``:
+        three entries (one per stage) of [B,143,3] arrays / parameter dicts of [B,.] tensors; ``save_loss``
+        maps every key of the reference's ``save_loss`` to an array [n_iterations, B]."""
+        self.bm = self.bm_male if gender == 'male' else self.bm_female
+        if self.bm is None:
+            raise ValueError('no body model was created for gender %r' % gender)
+        self.faces = self.bm.faces
+        B = self.batch_size
+        smplxparams_list, markers_fit_list = [], []
+        best_eval = torch.full((B,), 10000.0, device=self.device)
+        best_params, best_markers = None, None
+        hist = {k: [] for k in LOSS_KEYS + COUNT_KEYS}
+
+        for ss, optimizer in enumerate(self.optimizers):
+            markers_fit = None
+            for ii in range(self.num_iter[ss]):
+                alpha = min(ii / self.num_iter[ss] * 2, 1)
+                optimizer.zero_grad()
+                (loss, loss_dict, markers_fit, body_param, vertices_info, _rh, _rn, _h2o, _o2h) = self.calc_loss_contact_map(
+                    body_markers, verts_object, normal_object, object_contact, markers_contact, gender, betas, ss, alpha)
+                loss.sum().backward()
+                optimizer.step()
+                for k in LOSS_KEYS:
+                    hist[k].append(loss_dict[k])
+                for k in COUNT_KEYS:
+                    hist[k].append(vertices_info[k])
+                if self.verbose and log_every and not (ii + 1) % log_every:
+                    self.logger('[INFO][fitting][stage%d] iter=%d, mean loss %.5f' % (ss, ii, float(loss.mean())))
+                if not self.only_rec and ss == 2 and ii > 200:
+                    # best-of-iteration snapshot (:430-447): parameters AFTER the step, markers from before it
+                    ev = loss.detach()
+                    better = ev < best_eval
+                    snap = self._snapshot()
+                    mk = markers_fit.detach()
+                    if best_params is None:
+                        best_params = {k: v.clone() for k, v in snap.items()}
+                        best_markers = mk.clone()
+                    else:
+                        for k in snap:
+                            best_params[k] = torch.where(better[:, None], snap[k], best_params[k])
+                        best_markers = torch.where(better[:, None, None], mk, best_markers)
+                    best_eval = torch.where(better, ev, best_eval)
+            final = self._snapshot()
+            if ss == 2 and not self.only_rec and best_params is not None:
+                # a candidate whose loss never dropped below 10000 keeps its final parameters (tmp_info is None, :464)
+                never = best_eval >= 10000.0
+                out = {k: torch.where(never[:, None], final[k], best_params[k]) for k in final}
+                mfit = torch.where(never[:, None, None], markers_fit.detach(), best_markers)
+            else:
+                out, mfit = final, (markers_fit.detach() if markers_fit is not None else None)
+            smplxparams_list.append(out)
+            markers_fit_list.append(None if mfit is None else mfit.cpu().numpy())
+        self.reset()
+        save_loss = {k: (torch.stack(v).cpu().numpy() if v else np.zeros((0, B))) for k, v in hist.items()}
+        return markers_fit_list, smplxparams_list, save_loss
