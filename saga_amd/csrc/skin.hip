@@ -92,7 +92,7 @@ __global__ void joints_fwd_kernel(const float* __restrict__ chain, const float* 
 }
 
 // ---- backward of the joints output -----------------------------------------------------------------------
-// g_joints [B,NJO,3] -> g_pj [B,55,3] (compact), g_jsum [B,3] (sum over all joints -> d transl), and the
+// g_joints [B,NJO,3] -> g_pj [B,55,3] (compact), g_jsum [B,3] (direct d transl of the joints output), and the
 // vertex-picked / landmark gradients scatter-added into gv [B,V,3] (gv already holds g_vertices or zeros).
 // One block of 64 threads per candidate; landmarks share vertices, so the adds use (agent-scope) float atomics.
 __global__ void joints_bwd_kernel(const float* __restrict__ g_joints, const int32_t* __restrict__ extra_verts,
@@ -103,9 +103,17 @@ __global__ void joints_bwd_kernel(const float* __restrict__ g_joints, const int3
     const int b = blockIdx.x, t = threadIdx.x;
     const float* g = g_joints + (size_t)b * NJO * 3;
     float s[3] = {0, 0, 0};
+    // d transl: the 55 posed joints get `+ transl` directly; picked vertices inherit it through the vertices
+    // (their gradient reaches transl via sum_v gv); a landmark is sum_k bary_k (v_k - t) + t, so besides the
+    // vertex path it contributes g * (1 - sum_k bary_k) directly.
     for (int j = t; j < NJO; j += 64) {
         const float gx = g[j * 3], gy = g[j * 3 + 1], gz = g[j * 3 + 2];
-        s[0] += gx; s[1] += gy; s[2] += gz;
+        float direct = j < NJ ? 1.f : 0.f;
+        if (j >= NJ + E) {
+            const int l = j - NJ - E;
+            direct = 1.f - ((lmk_bary[l * 3] + lmk_bary[l * 3 + 1]) + lmk_bary[l * 3 + 2]);
+        }
+        s[0] += gx * direct; s[1] += gy * direct; s[2] += gz * direct;
         if (j < NJ) {
             g_pj[(size_t)b * small_stride + j * 3] = gx;
             g_pj[(size_t)b * small_stride + j * 3 + 1] = gy;

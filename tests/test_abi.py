@@ -1,0 +1,83 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol include/saga_hip.h
+declares; argument errors come back as codes + messages (no compute call needs a GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'saga_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(saga_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_symbols_all_exported_and_bound():
+    from saga_amd import _lib
+    lib = _lib.load()
+    names = _declared_symbols()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), 'libsaga_hip.so does not export %s' % n
+        assert n in _lib.PROTOTYPES, '%s is declared in the header but not bound in saga_amd/_lib.py' % n
+    assert set(_lib.PROTOTYPES) == set(names)
+    assert lib.saga_version() >= 100
+
+
+def test_argument_errors_have_messages():
+    from saga_amd import _lib
+    lib = _lib.load()
+    rc = lib.saga_chamfer_fwd(None, None, None, None, None, None, 1, 4, 0, None)
+    assert rc == -1 and b'empty cloud' in lib.saga_last_error()
+    rc = lib.saga_rodrigues_fwd(None, None, 5, None)
+    assert rc == -1
+    rc = lib.saga_smplx_fwd(None, None, None, None, None, None, None, None, None, None, None, None, 1, None)
+    assert rc == -1 and b'null model' in lib.saga_last_error()
+    assert lib.saga_chamfer_fwd(None, None, None, None, None, None, 0, 4, 4, None) == 0     # empty batch is a no-op
+
+
+def test_constants_match_header():
+    from saga_amd import _lib
+    text = open(os.path.join(ROOT, 'include', 'saga_hip.h')).read()
+    get = lambda n: int(re.search(r'#define\s+%s\s+(\d+)' % n, text).group(1))
+    assert get('SAGA_FEAT_K') == _lib.FEAT_K and get('SAGA_N_ALIGN') == _lib.N_ALIGN
+    assert get('SAGA_BWD_SPLITK') == _lib.BWD_SPLITK and get('SAGA_DA_STRIDE') == _lib.DA_STRIDE
+
+
+def test_product_refuses_cpu_tensors():
+    import saga_amd.chamfer_distance as chd
+    from saga_amd.smplx.lbs import batch_rodrigues
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        chd.ChamferDistance(torch.zeros(1, 3, 3), torch.zeros(1, 3, 3))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        batch_rodrigues(torch.zeros(2, 3))
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'saga_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_smplx_create_path_logic_and_dropin_alias(tmp_path):
+    from saga_amd.synthetic import small_vertex_ids, write_body_model
+    import saga_amd
+    write_body_model(str(tmp_path), gender='male', seed=1, n_verts=60, n_faces=100)
+    import sys
+    sys.path.insert(0, saga_amd.install_dropins())
+    import smplx
+    from smplx.lbs import batch_rodrigues  # noqa: F401  (objectmodel.py:6 import form)
+    bm = smplx.create(str(tmp_path), model_type='smplx', gender='male', ext='npz', num_pca_comps=24, batch_size=4,
+                      create_transl=True, vertex_ids=small_vertex_ids(60))
+    assert bm.faces.shape == (100, 3) and bm.betas.shape == (4, 10) and bm.left_hand_pose.shape == (4, 24)
+    assert bm.num_joints_out == 127
+    with pytest.raises(FileNotFoundError):
+        smplx.create(str(tmp_path), model_type='smplx', gender='female', ext='npz')
+    import chamfer_distance as chd
+    assert callable(chd.ChamferDistance)

@@ -1,0 +1,112 @@
+"""GPU parity: chamfer NN / point2point_signed / vertex normals against the oracle and the reference goldens.
+Bar: nearest-neighbour indices and squared distances bit-exact (integer / index work)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import chamfer_ref, geometry_ref
+from tests.helpers import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(x, y):
+    import saga_amd.chamfer_distance as chd
+    d1, d2, i1, i2 = chd.ChamferDistance(x.cuda(), y.cuda())
+    r1, r2, j1, j2 = chamfer_ref.chamfer_distance(x, y)
+    assert i1.dtype == torch.int32 and i2.dtype == torch.int32
+    assert_same(i1.cpu().numpy(), j1.numpy())
+    assert_same(i2.cpu().numpy(), j2.numpy())
+    assert_same(d1.cpu().numpy(), r1.numpy())
+    assert_same(d2.cpu().numpy(), r2.numpy())
+
+
+@pytest.mark.parametrize('N,P1,P2', [(1, 1, 1), (2, 143, 2048), (2, 778, 2048), (3, 37, 53), (1, 1500, 1025), (2, 300, 4097)])
+def test_chamfer_exact(N, P1, P2):
+    g = torch.Generator().manual_seed(P1 * 7 + P2)
+    _check(torch.randn(N, P1, 3, generator=g) * 0.1, torch.randn(N, P2, 3, generator=g) * 0.1)
+
+
+def test_chamfer_ties_lowest_index():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 64, 3, generator=g)
+    y = torch.randn(2, 1200, 3, generator=g)
+    y[:, 1100] = y[:, 7]        # duplicates across an LDS tile boundary
+    y[:, 300] = y[:, 7]
+    x[:, 40] = x[:, 11]
+    _check(x, y)
+    # on a lattice nearly everything ties
+    lat = torch.stack(torch.meshgrid(torch.arange(8.), torch.arange(8.), torch.arange(4.), indexing='ij'), -1).reshape(1, -1, 3)
+    _check(lat + 0.5, lat)
+
+
+def test_chamfer_both_call_forms_and_errors():
+    import saga_amd.chamfer_distance as chd
+    x = torch.randn(1, 5, 3).cuda()
+    y = torch.randn(1, 6, 3).cuda()
+    a = chd.ChamferDistance(x, y)
+    b = chd.ChamferDistance()(x, y)
+    for s, t in zip(a, b):
+        assert torch.equal(s, t)
+    with pytest.raises(ValueError):
+        chd.ChamferDistance(x, torch.randn(2, 6, 3).cuda())
+    with pytest.raises(RuntimeError):
+        chd.ChamferDistance(x, torch.zeros(1, 0, 3).cuda())     # empty cloud has no neighbour
+    with pytest.raises(RuntimeError):
+        chd.ChamferDistance(x.cpu(), y.cpu())                   # no CPU fallback
+
+
+def test_chamfer_backward_matches_autograd_of_gathered_distance():
+    import saga_amd.chamfer_distance as chd
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 50, 3, generator=g, dtype=torch.float64)
+    y = torch.randn(2, 70, 3, generator=g, dtype=torch.float64)
+    w1 = torch.randn(2, 50, generator=g, dtype=torch.float64)
+    w2 = torch.randn(2, 70, generator=g, dtype=torch.float64)
+    xr, yr = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    _, _, i1, i2 = chamfer_ref.chamfer_distance(x.float(), y.float())
+    d1 = ((xr - yr.gather(1, i1.long()[..., None].expand(-1, -1, 3))) ** 2).sum(-1)
+    d2 = ((yr - xr.gather(1, i2.long()[..., None].expand(-1, -1, 3))) ** 2).sum(-1)
+    ((d1 * w1).sum() + (d2 * w2).sum()).backward()
+    xh, yh = x.float().cuda().requires_grad_(True), y.float().cuda().requires_grad_(True)
+    h1, h2, _, _ = chd.ChamferDistance(xh, yh)
+    ((h1 * w1.float().cuda()).sum() + (h2 * w2.float().cuda()).sum()).backward()
+    np.testing.assert_allclose(xh.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(yh.grad.cpu().numpy(), yr.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('name', ['markers', 'rhand'])
+def test_point2point_signed_against_reference_golden(golden, name):
+    """The product function on the HIP NN search against outputs of the reference's own function."""
+    from saga_amd.geometry import point2point_signed
+    g = golden('p2p_signed.npz')
+    c = lambda k: torch.from_numpy(g[f'{name}_{k}']).cuda()
+    x = c('x').requires_grad_(True)
+    y2x, x2y, yidx, xidx = point2point_signed(x, c('y'), c('xn'), c('yn'))
+    assert_same(yidx.cpu().numpy(), g[f'{name}_yidx'])
+    assert_same(xidx.cpu().numpy(), g[f'{name}_xidx'])
+    np.testing.assert_allclose(y2x.detach().cpu().numpy(), g[f'{name}_y2x'], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(x2y.detach().cpu().numpy(), g[f'{name}_x2y'], rtol=1e-5, atol=1e-7)
+    ((y2x * c('wy')).sum() + (x2y * c('wx')).sum()).backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[f'{name}_grad_x'], rtol=1e-4, atol=1e-5)
+
+
+def test_point2point_signed_value_error():
+    from saga_amd.geometry import point2point_signed
+    with pytest.raises(ValueError):
+        point2point_signed(torch.zeros(2, 5, 3).cuda(), torch.zeros(3, 7, 3).cuda())
+
+
+def test_vertex_normals_full_and_subset(body_model_dir):
+    from saga_amd.geometry import vertex_normals, vertex_normals_subset
+    from tests.helpers import make_hip_model
+    bm = make_hip_model(body_model_dir, 3)
+    g = torch.Generator().manual_seed(2)
+    verts = torch.randn(3, 10475, 3, generator=g)
+    ref = geometry_ref.vertex_normals(verts.double(), torch.from_numpy(bm.faces)).numpy()
+    full = vertex_normals(bm, verts.cuda()).cpu().numpy()
+    # float32 on the device vs Open3D's double: compare directions
+    assert np.abs(full - ref).max() < 1e-4
+    sel = torch.arange(7331, 7331 + 778, dtype=torch.int32).cuda()
+    sub = vertex_normals_subset(bm, verts.cuda(), sel).cpu().numpy()
+    assert_same(sub, full[:, 7331:7331 + 778])

@@ -1,0 +1,81 @@
+"""GPU parity of the whole iteration: saga_amd.FittingOP (HIP) against the CPU oracle restating
+WholeGraspPose/models/fittingop.py:137-244 (loss) and :343-499 (3-stage Adam loop).
+Bar (north_star): losses within 1e-4 relative."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fitting_ref, loss_ref
+from saga_amd.synthetic import make_candidate_params, make_grasp_targets, make_object_cloud
+from tests.helpers import load_oracle_model, rel_err
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-4
+
+
+def _setup(body_model_dir, B, num_iter=(3, 3, 3), seed=1234, scale=0.3):
+    from saga_amd.fitting import FittingOP, load_grasp_indices
+    from saga_amd.vposer import VPoserDecoder
+    vp = VPoserDecoder(seed=0)
+    op = FittingOP({'batch_size': B, 'device': 'cuda', 'body_model_path': body_model_dir, 'vposer': vp,
+                    'genders': ('male',), 'num_iter': list(num_iter), 'verbose': False})
+    idx_np = load_grasp_indices()
+    idx = {'markers_143': torch.from_numpy(idx_np['markers_143']), 'foot': torch.from_numpy(idx_np['foot']),
+           'rhand': torch.from_numpy(idx_np['rhand']), 'v_weights': torch.from_numpy(idx_np['rhand_weight'])}
+    verts_o, normals_o, _, _ = make_object_cloud(B, seed=0)
+    markers, mc, oc = make_grasp_targets(B, verts_o, seed=4815)
+    var_np = make_candidate_params(B, seed=seed, scale=scale)
+    data = dict(markers=markers, mc=mc, oc=oc, verts_o=verts_o, normals_o=normals_o)
+    return op, vp, idx, var_np, data
+
+
+@pytest.mark.parametrize('stage', [0, 1, 2])
+def test_loss_and_gradients_match_oracle(body_model_dir, stage):
+    B = 3
+    op, vp, idx, var_np, d = _setup(body_model_dir, B)
+    op.bm = op.bm_male
+    op.set_variables(var_np)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    loss, loss_dict, mk, bp, info, *_ = op.calc_loss_contact_map(cu(d['markers']), cu(d['verts_o']), cu(d['normals_o']),
+                                                                 cu(d['oc']), cu(d['mc']), 'male', None, stage, 1.0)
+    loss.sum().backward()
+
+    bm = load_oracle_model(body_model_dir, B, dtype=torch.float64)
+    var = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in var_np.items()}
+    t = lambda a: torch.from_numpy(a).double()
+    total, ld, cnt, aux = loss_ref.loss_batched(bm, var, vp.weights_dict(torch.float64), idx, t(d['markers']), t(d['verts_o']),
+                                                t(d['normals_o']), t(d['oc']), t(d['mc']), stage)
+    total.sum().backward()
+    assert np.abs(mk.detach().cpu().numpy() - aux['markers_rec'].detach().numpy()).max() < 1e-5
+    for k in loss_ref.LOSS_KEYS:
+        a, b = loss_dict[k].cpu().numpy(), ld[k].detach().numpy()
+        np.testing.assert_allclose(a, b, rtol=LOSS_RTOL, atol=1e-9, err_msg=k)
+    for k in loss_ref.COUNT_KEYS:
+        assert np.abs(info[k].cpu().numpy() - cnt[k].numpy()).max() <= 2, k    # sign flips only at |dot| ~ 0
+    active = {0: ['transl_rec', 'glo_rot_rec'], 1: ['betas', 'transl_rec', 'glo_rot_rec', 'vpose_rec'],
+              2: ['betas', 'transl_rec', 'glo_rot_rec', 'vpose_rec', 'hand_pose', 'eye_pose']}[stage]
+    for k in active:
+        e = rel_err(getattr(op, k).grad.cpu().numpy(), var[k].grad.numpy())
+        assert e < 2e-3, (k, e)
+
+
+def test_short_fitting_trajectory_matches_oracle(body_model_dir):
+    """A few Adam iterations per stage from the reference's reset state: per-iteration loss curves agree."""
+    B = 2
+    num_iter = (4, 4, 4)
+    op, vp, idx, _, d = _setup(body_model_dir, B, num_iter=num_iter)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    mfit, params, save_loss = op.fitting(cu(d['markers']), cu(d['oc']), cu(d['mc']), cu(d['verts_o']), cu(d['normals_o']), 'male')
+    assert save_loss['total'].shape == (sum(num_iter), B)
+    bm = load_oracle_model(body_model_dir, B, dtype=torch.float32)
+    t = lambda a: torch.from_numpy(a)
+    p_ref, m_ref, hist = fitting_ref.fitting(bm, vp.weights_dict(torch.float32), idx, t(d['markers']), t(d['oc']), t(d['mc']),
+                                             t(d['verts_o']), t(d['normals_o']), num_iter=num_iter)
+    hist = torch.stack(hist).numpy()
+    np.testing.assert_allclose(save_loss['total'], hist, rtol=2e-3)
+    np.testing.assert_allclose(save_loss['total'][0], hist[0], rtol=LOSS_RTOL)
+    for k in params[-1]:
+        assert params[-1][k].shape[0] == B
+        np.testing.assert_allclose(params[-1][k].cpu().numpy(), p_ref[-1][k].numpy(), atol=5e-3, err_msg=k)
+    assert mfit[-1].shape == (B, 143, 3)

@@ -1,0 +1,140 @@
+"""GPU parity: saga_amd.smplx (HIP) against the float64 CPU oracle.
+Bars (BASELINE.json north_star): vertices and joints within 1e-5 m absolute in FP32; gradients are
+compared relative to the largest oracle gradient entry (1e-4)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load_oracle_model, make_hip_model, random_body_inputs, rel_err, to_cuda
+
+pytestmark = pytest.mark.gpu
+
+VERT_TOL = 1e-5      # metres, absolute
+GRAD_TOL = 2e-4      # relative to max |grad|
+
+
+def _fwd_bwd(root, B, small, seed, use_joints=True, use_verts=True):
+    ref = load_oracle_model(root, B, small=small)
+    hip = make_hip_model(root, B, small=small)
+    inp = random_body_inputs(B, seed=seed)
+    inp_ref = {k: v.clone().requires_grad_(True) for k, v in inp.items()}
+    inp_hip = to_cuda(inp, requires_grad=True)
+    out_ref = ref(**inp_ref)
+    out_hip = hip(return_verts=True, **inp_hip)
+    g = torch.Generator().manual_seed(seed + 100)
+    wv = torch.randn(out_ref['vertices'].shape, generator=g, dtype=torch.float64)
+    wj = torch.randn(out_ref['joints'].shape, generator=g, dtype=torch.float64)
+    loss_ref = 0
+    loss_hip = 0
+    if use_verts:
+        loss_ref = loss_ref + (out_ref['vertices'] * wv).sum()
+        loss_hip = loss_hip + (out_hip.vertices * wv.float().cuda()).sum()
+    if use_joints:
+        loss_ref = loss_ref + (out_ref['joints'] * wj).sum()
+        loss_hip = loss_hip + (out_hip.joints * wj.float().cuda()).sum()
+    loss_ref.backward()
+    loss_hip.backward()
+    return out_ref, out_hip, inp_ref, inp_hip
+
+
+@pytest.mark.parametrize('B', [1, 3, 130])
+def test_forward_small_dense_weights(small_model_dir, B):
+    ref = load_oracle_model(small_model_dir, B, small=True)
+    hip = make_hip_model(small_model_dir, B, small=True)
+    inp = random_body_inputs(B, seed=B)
+    out_ref = ref(**inp)
+    out_hip = hip(return_verts=True, **to_cuda(inp))
+    assert out_hip.vertices.shape == (B, 203, 3) and out_hip.joints.shape == (B, 127, 3)
+    assert np.abs(out_hip.vertices.detach().cpu().numpy() - out_ref['vertices'].numpy()).max() < VERT_TOL
+    assert np.abs(out_hip.joints.detach().cpu().numpy() - out_ref['joints'].numpy()).max() < VERT_TOL
+
+
+def test_forward_full_mesh(body_model_dir):
+    B = 5
+    ref = load_oracle_model(body_model_dir, B)
+    hip = make_hip_model(body_model_dir, B)
+    inp = random_body_inputs(B, seed=42)
+    out_ref = ref(**inp)
+    out_hip = hip(return_verts=True, return_full_pose=True, **to_cuda(inp))
+    assert out_hip.vertices.shape == (B, 10475, 3) and out_hip.joints.shape == (B, 127, 3)
+    dv = np.abs(out_hip.vertices.detach().cpu().numpy() - out_ref['vertices'].numpy()).max()
+    dj = np.abs(out_hip.joints.detach().cpu().numpy() - out_ref['joints'].numpy()).max()
+    assert dv < VERT_TOL and dj < VERT_TOL, (dv, dj)
+    np.testing.assert_allclose(out_hip.full_pose.detach().cpu().numpy(), out_ref['full_pose'].numpy(), atol=1e-6)
+
+
+def test_defaults_are_module_parameters(small_model_dir):
+    """Every argument optional: defaults = zero parameters of shape [batch_size, .] (fittingop.py:149 passes
+    no jaw_pose / expression)."""
+    B = 2
+    ref = load_oracle_model(small_model_dir, B, small=True)
+    hip = make_hip_model(small_model_dir, B, small=True)
+    out_ref = ref()
+    out_hip = hip()
+    assert np.abs(out_hip.vertices.detach().cpu().numpy() - out_ref['vertices'].numpy()).max() < VERT_TOL
+    inp = random_body_inputs(B, seed=9)
+    keys = ['transl', 'global_orient', 'betas', 'body_pose', 'left_hand_pose', 'right_hand_pose', 'leye_pose', 'reye_pose']
+    sub = {k: inp[k] for k in keys}
+    out_ref = ref(**sub)
+    out_hip = hip(return_verts=True, **to_cuda(sub))
+    assert np.abs(out_hip.vertices.detach().cpu().numpy() - out_ref['vertices'].numpy()).max() < VERT_TOL
+
+
+@pytest.mark.parametrize('mode', ['verts', 'joints', 'both'])
+def test_backward_small(small_model_dir, mode):
+    out_ref, out_hip, inp_ref, inp_hip = _fwd_bwd(small_model_dir, 6, True, 5, use_joints=mode != 'verts',
+                                                 use_verts=mode != 'joints')
+    for k in inp_ref:
+        e = rel_err(inp_hip[k].grad.cpu().numpy(), inp_ref[k].grad.numpy())
+        assert e < GRAD_TOL, (k, e)
+
+
+def test_backward_full_mesh(body_model_dir):
+    out_ref, out_hip, inp_ref, inp_hip = _fwd_bwd(body_model_dir, 4, False, 7)
+    for k in inp_ref:
+        e = rel_err(inp_hip[k].grad.cpu().numpy(), inp_ref[k].grad.numpy())
+        assert e < GRAD_TOL, (k, e)
+
+
+def test_backward_zero_pose_finite(small_model_dir):
+    """Reset state of the optimiser: zero hand / eye pose (fittingop.py:134-135) must give finite grads."""
+    B = 2
+    ref = load_oracle_model(small_model_dir, B, small=True)
+    hip = make_hip_model(small_model_dir, B, small=True)
+    z = {k: torch.zeros_like(v) for k, v in random_body_inputs(B).items()}
+    zr = {k: v.clone().requires_grad_(True) for k, v in z.items()}
+    zh = to_cuda(z, requires_grad=True)
+    w = torch.randn(B, 203, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    (ref(**zr)['vertices'] * w).sum().backward()
+    (hip(**zh).vertices * w.float().cuda()).sum().backward()
+    for k in zr:
+        gh = zh[k].grad.cpu().numpy()
+        assert np.isfinite(gh).all(), k
+        assert rel_err(gh, zr[k].grad.numpy()) < GRAD_TOL, k
+
+
+def test_batch_rodrigues_parity():
+    from oracle.smplx_ref import batch_rodrigues as ref_rod
+    from saga_amd.smplx.lbs import batch_rodrigues
+    g = torch.Generator().manual_seed(3)
+    r = torch.randn(257, 3, generator=g, dtype=torch.float64)
+    r[0] = 0
+    r[1] = torch.tensor([0.0, 0.0, 3.1])
+    rr = r.clone().requires_grad_(True)
+    rh = r.float().cuda().requires_grad_(True)
+    w = torch.randn(257, 3, 3, generator=g, dtype=torch.float64)
+    Rr = ref_rod(rr)
+    Rh = batch_rodrigues(rh)
+    assert np.abs(Rh.detach().cpu().numpy() - Rr.detach().numpy()).max() < 2e-6
+    (Rr * w).sum().backward()
+    (Rh * w.float().cuda()).sum().backward()
+    assert rel_err(rh.grad.cpu().numpy(), rr.grad.numpy()) < 1e-4
+
+
+def test_cpu_tensor_is_rejected(small_model_dir):
+    import saga_amd.smplx as smplx
+    from saga_amd.synthetic import small_vertex_ids
+    bm = smplx.create(small_model_dir, model_type='smplx', gender='male', ext='npz', num_pca_comps=24, batch_size=1,
+                      vertex_ids=small_vertex_ids(203))
+    with pytest.raises(RuntimeError):
+        bm()        # parameters still on the CPU: no fallback
