@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Benchmark of the GraspPose-Opt hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one fitting iteration of stage 3 (every loss term active) over B candidates on each GPU:
+optimizer.zero_grad, 6D->aa + VPoser decode, SMPL-X forward (full 10,475-vertex mesh), hand vertex normals,
+two bidirectional nearest-neighbour searches against 2,048 object points, signed distances + contact /
+collision losses, backward to the optimiser variables, Adam step.  Inputs are synthetic (random-init
+shape-compatible body model, ellipsoid object clouds, seeded candidates) and resident in HBM before the timed
+region.  Candidates shard across ranks with no data-path collective ("weak" scaling: B per GPU is fixed);
+the end-of-fit all-gather for best-of-N runs once, after the timed region.
+
+Rank 0 prints ONE JSON line; see DESIGN.md 'Measurement' for the roofline arithmetic.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_TFLOPS = 157.3     # MI355X dense FP32 (vector = matrix), /opt/skills/guides/MI355X_MICROARCH.md
+V, K_FEAT = 10475, 512
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=4096, help='candidates per GPU')
+    ap.add_argument('--obj-points', type=int, default=2048)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=16)
+    ap.add_argument('--cpu-iters', type=int, default=64)
+    return ap.parse_args()
+
+
+def build_problem(B, n_obj, rank, model_root, device):
+    from saga_amd.fitting import FittingOP
+    from saga_amd.synthetic import make_candidate_params, make_grasp_targets, make_object_cloud
+    from saga_amd.vposer import VPoserDecoder
+    vp = VPoserDecoder(seed=0)
+    op = FittingOP({'batch_size': B, 'device': device, 'body_model_path': model_root, 'vposer': vp, 'genders': ('male',)})
+    op.bm = op.bm_male
+    op.set_variables(make_candidate_params(B, seed=1234 + 7919 * rank, scale=0.3))
+    vo, no, _, _ = make_object_cloud(B, n_points=n_obj, seed=rank)
+    mk, mc, oc = make_grasp_targets(B, vo, seed=4815 + rank)
+    cu = lambda a: torch.from_numpy(a).to(device)
+    data = dict(markers=cu(mk), mc=cu(mc), oc=cu(oc), vo=cu(vo), no=cu(no))
+    return op, vp, data
+
+
+def step(op, d, optimizer):
+    optimizer.zero_grad(set_to_none=True)
+    loss, *_ = op.calc_loss_contact_map(d['markers'], d['vo'], d['no'], d['oc'], d['mc'], 'male', None, 2, 1.0)
+    loss.sum().backward()
+    optimizer.step()
+    return loss
+
+
+def cpu_baseline(model_root, vp, n_obj, batch, iters):
+    """The oracle (CPU restatement of the reference iteration, PyTorch eager FP32) timed on the host cores."""
+    from oracle import loss_ref, smplx_ref
+    from saga_amd.fitting import load_grasp_indices
+    from saga_amd.synthetic import make_candidate_params, make_grasp_targets, make_object_cloud
+    threads = torch.get_num_threads()
+    data = dict(np.load(os.path.join(model_root, 'smplx', 'SMPLX_MALE.npz')))
+    bm = smplx_ref.SMPLXRef(data, num_pca_comps=24, batch_size=batch, dtype=torch.float32)
+    idx_np = load_grasp_indices()
+    idx = {'markers_143': torch.from_numpy(idx_np['markers_143']), 'foot': torch.from_numpy(idx_np['foot']),
+           'rhand': torch.from_numpy(idx_np['rhand']), 'v_weights': torch.from_numpy(idx_np['rhand_weight'])}
+    var = {k: torch.from_numpy(v).requires_grad_(True) for k, v in make_candidate_params(batch, seed=1234, scale=0.3).items()}
+    vo, no, _, _ = make_object_cloud(batch, n_points=n_obj, seed=0)
+    mk, mc, oc = make_grasp_targets(batch, vo, seed=4815)
+    t = torch.from_numpy
+    w = vp.weights_dict(torch.float32)
+
+    def one():
+        for v in var.values():
+            v.grad = None
+        total, *_ = loss_ref.loss_batched(bm, var, w, idx, t(mk), t(vo), t(no), t(oc), t(mc), 2)
+        total.sum().backward()
+
+    one()                                   # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    dt = time.perf_counter() - t0
+    return batch * iters / dt, threads, dt
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    assert torch.cuda.is_available(), 'bench.py needs a ROCm GPU'
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    from saga_amd import _lib
+    from saga_amd.distributed import best_of_n, gather_candidates
+    from saga_amd.synthetic import write_body_model
+
+    B, n_obj = args.batch, args.obj_points
+    tmp = tempfile.TemporaryDirectory()
+    write_body_model(tmp.name, gender='male', seed=7)
+    op, vp, d = build_problem(B, n_obj, rank, tmp.name, str(device))
+    optimizer = op.optimizer_s3
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(op, d, optimizer)
+    barrier()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(op, d, optimizer)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    prof = _lib.profile_read()
+
+    t_max = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+
+    # end-of-fit exchange (untimed): all-gather (loss, parameters) of every candidate, best-of-N per group of 8
+    with torch.no_grad():
+        params = {k: v.detach() for k, v in op.body_params().items()}
+    gl, gp = gather_candidates(loss.detach(), params, n_total=B * world)
+    _, best_loss, _ = best_of_n(gl, gp, group_size=8)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        iters_per_s = world * args.steps / elapsed              # B-candidate iterations over all GPUs
+        # dominant kernel: the FP32-MFMA blend contraction (forward + backward launches are the same kernel template)
+        gemm_ms = prof['blend_gemm_fwd'][0] + prof['blend_gemm_bwd'][0]
+        gemm_n = prof['blend_gemm_fwd'][1] + prof['blend_gemm_bwd'][1]
+        flop_per_launch = 2.0 * B * (3 * V) * K_FEAT           # algorithmic: [B,512] x [512,31425], fwd == bwd
+        achieved = flop_per_launch / (gemm_ms / max(gemm_n, 1) * 1e-3) / 1e12 if gemm_n else None
+        kernels = {k: {'ms_per_step': round(ms / args.steps, 4), 'launches_per_step': n / args.steps}
+                   for k, (ms, n) in prof.items() if n}
+        out = {
+            'metric': 'GraspPose-Opt fwd+bwd iters/sec at B=4096, 2048 obj pts (1/2/4/8 GPU)',
+            'value': round(iters_per_s, 4),
+            'unit': 'iterations/s (each = one fwd+bwd+Adam iteration over B=%d candidates per GPU, summed over GPUs)' % B,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'GraspPose-Opt stage-3 iteration: SMPL-X fwd+bwd (V=10475, full mesh) + hand normals + '
+                                   '2 bidirectional NN vs %d object points + contact/collision losses + Adam' % n_obj,
+                       'candidates_per_gpu': B, 'candidates_total': B * world, 'object_points': n_obj,
+                       'candidate_iterations_per_s': round(iters_per_s * B, 1),
+                       'parallelism': 'candidates sharded, %d rank(s), no data-path collective' % world,
+                       'best_of_8_mean_loss': float(best_loss.mean()), 'kernels': kernels},
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_f32_kernel (blend contraction, fwd+bwd launches)',
+                         'achieved': None if achieved is None else round(achieved, 2), 'peak': PEAK_F32_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': None if achieved is None else round(achieved / PEAK_F32_TFLOPS, 4),
+                         'traffic': None},
+        }
+        if not args.no_cpu_baseline:
+            cand_per_s, threads, dt = cpu_baseline(tmp.name, vp, n_obj, args.cpu_batch, args.cpu_iters)
+            out['cpu_baseline'] = {
+                'value': round(cand_per_s / B, 6), 'unit': 'iterations/s at B=%d (extrapolated from candidate-iterations/s)' % B,
+                'cores': threads, 'kind': 'port',
+                'sample': '%d fwd+bwd iterations of the oracle at B=%d candidates x %d object points (%.1f s), '
+                          '%.2f candidate-iterations/s' % (args.cpu_iters, args.cpu_batch, n_obj, dt, cand_per_s)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    tmp.cleanup()
+
+
+if __name__ == '__main__':
+    main()

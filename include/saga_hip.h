@@ -142,6 +142,72 @@ int saga_vertex_normals(const saga_model_t* m, const float* verts, float* normal
 int saga_vertex_normals_subset(const saga_model_t* m, const float* verts, const int32_t* sel, int n_sel,
                                float* normals, int B, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused contact / penetration loss.  Replaces, for B independent candidates, everything
+ * FittingOP.calc_loss_contact_map does between the SMPL-X call and the weighted sum
+ * (WholeGraspPose/models/fittingop.py:152-212): the marker / foot / right-hand gathers, the Open3D
+ * hand normals (:158-164), both point2point_signed calls (:183-184 -> utils/train_helper.py:17-86)
+ * and the per-candidate means.  Index tables are DEVICE arrays built once by the host from
+ * body_utils (fittingop.py:86-124); `unique_ids` is the sorted union of marker / hand / foot ids
+ * and the *_slot arrays map every table entry to its position in it.
+ *
+ * terms [B,SAGA_GRASP_NTERMS]: 0 rec (:168)  1 body_rec (:169)  2 foot = 0.1*mean|z| (:173)
+ *   3 marker contact (:190)  4 object contact (:191)  5 prior contact (:210)  6 hand collision (:211)
+ *   7 object collision (:212)  8-11 counts: hand colli, obj colli, contact, hand markers colli (:238-242)
+ * Also returned (what calc_loss_contact_map hands back / what the backward needs):
+ *   markers_rec [B,M,3], hand_rec [B,H,3], hand_normals [B,H,3], h2o_marker [B,M] (unsigned, :183 quirk),
+ *   h2o_signed [B,H], o2h_signed [B,O], idx_m2o [B,M], idx_h2o [B,H], idx_o2h [B,O] (int32)
+ * saga_grasp_loss_bwd: g_terms [B,SAGA_GRASP_NTERMS] (entries 0..7 used) -> g_verts [B,V,3] (fully
+ * written: zero-filled, then the touched vertices).
+ * ------------------------------------------------------------------------------------------ */
+#define SAGA_GRASP_NTERMS 16
+typedef struct {
+    int32_t n_markers, n_hand, n_foot, n_body_markers, n_unique;
+    const int32_t* marker_ids;   /* [n_markers] vertex ids (markers_143) */
+    const int32_t* hand_ids;     /* [n_hand]    right-hand vertex ids    */
+    const int32_t* foot_ids;     /* [n_foot]                              */
+    const float*   hand_weights; /* [n_hand]    rhand_weight.npy          */
+    const int32_t* unique_ids;   /* [n_unique]                            */
+    const int32_t* marker_slot;  /* [n_markers] index into unique_ids     */
+    const int32_t* hand_slot;    /* [n_hand]                              */
+    const int32_t* foot_slot;    /* [n_foot]                              */
+} saga_grasp_tables_t;
+
+int saga_grasp_loss_fwd(const saga_model_t* m, const saga_grasp_tables_t* tables, const float* verts,
+                        const float* obj, const float* obj_normals, const float* markers_target,
+                        const float* c_markers, const float* c_object,
+                        float* terms, float* markers_rec, float* hand_rec, float* hand_normals,
+                        float* h2o_marker, float* h2o_signed, float* o2h_signed,
+                        int32_t* idx_m2o, int32_t* idx_h2o, int32_t* idx_o2h, int B, int O, void* stream);
+int saga_grasp_loss_bwd(const saga_model_t* m, const saga_grasp_tables_t* tables, const float* g_terms,
+                        const float* verts, const float* obj, const float* markers_target,
+                        const float* c_markers, const float* c_object, const float* markers_rec,
+                        const float* hand_rec, const float* h2o_signed, const float* o2h_signed,
+                        const int32_t* idx_m2o, const int32_t* idx_h2o, const int32_t* idx_o2h,
+                        float* g_verts, int B, int O, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-kernel timing for bench.py (no counterpart in the reference, whose only timing hook is the
+ * disabled `time per sample` log at WholeGraspPose/models/fittingop.py:376,491-492).
+ * When enabled, every kernel launch of the entry points above is bracketed by a hipEvent pair on
+ * the launch stream; saga_profile_read() synchronises them and returns, per kernel id, the summed
+ * elapsed milliseconds and the number of launches since the last read.  Not thread-safe.
+ * ------------------------------------------------------------------------------------------ */
+#define SAGA_PROF_POSE_FWD   0
+#define SAGA_PROF_BLEND_FWD  1   /* FP32-MFMA blend contraction, forward  */
+#define SAGA_PROF_SKIN_FWD   2
+#define SAGA_PROF_JOINTS     3
+#define SAGA_PROF_SKIN_BWD   4   /* g_v_posed + dA reduction */
+#define SAGA_PROF_BLEND_BWD  5   /* FP32-MFMA blend contraction, backward (split-K) */
+#define SAGA_PROF_POSE_BWD   6
+#define SAGA_PROF_CHAMFER    7   /* both scan directions of one saga_chamfer_fwd call */
+#define SAGA_PROF_NORMALS    8
+#define SAGA_PROF_GRASP_FWD  9   /* fused normals + NN + signed distances + loss terms */
+#define SAGA_PROF_GRASP_BWD  10
+#define SAGA_PROF_NKERNELS   11
+int saga_profile_enable(int on);
+int saga_profile_read(double* total_ms_host, int32_t* count_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,16 @@ class ModelDesc(ctypes.Structure):
     ]
 
 
+class GraspTables(ctypes.Structure):
+    _fields_ = [('n_markers', ctypes.c_int32), ('n_hand', ctypes.c_int32), ('n_foot', ctypes.c_int32),
+                ('n_body_markers', ctypes.c_int32), ('n_unique', ctypes.c_int32),
+                ('marker_ids', ctypes.c_void_p), ('hand_ids', ctypes.c_void_p), ('foot_ids', ctypes.c_void_p),
+                ('hand_weights', ctypes.c_void_p), ('unique_ids', ctypes.c_void_p), ('marker_slot', ctypes.c_void_p),
+                ('hand_slot', ctypes.c_void_p), ('foot_slot', ctypes.c_void_p)]
+
+
+GRASP_NTERMS = 16
+
 # name -> (restype, argtypes); every symbol include/saga_hip.h declares
 PROTOTYPES = {
     'saga_last_error': (ctypes.c_char_p, []),
@@ -54,7 +64,16 @@ PROTOTYPES = {
     'saga_vertex_normals': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_int, c_stream]),
     'saga_vertex_normals_subset': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_int_p, ctypes.c_int, c_float_p,
                                                   ctypes.c_int, c_stream]),
+    'saga_grasp_loss_fwd': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(GraspTables)] + [ctypes.c_void_p] * 16 +
+                            [ctypes.c_int, ctypes.c_int, c_stream]),
+    'saga_grasp_loss_bwd': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(GraspTables)] + [ctypes.c_void_p] * 14 +
+                            [ctypes.c_int, ctypes.c_int, c_stream]),
+    'saga_profile_enable': (ctypes.c_int, [ctypes.c_int]),
+    'saga_profile_read': (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),
 }
+
+PROF_KERNELS = ['pose_fwd', 'blend_gemm_fwd', 'skin_fwd', 'joints', 'skin_bwd', 'blend_gemm_bwd', 'pose_bwd',
+                'chamfer_nn', 'vertex_normals', 'grasp_loss_fwd', 'grasp_loss_bwd']
 
 _lib = None
 
@@ -100,3 +119,16 @@ def require_device(*tensors):
             raise RuntimeError('saga_amd ops run on the GPU only (got a %s tensor); there is no CPU fallback' % t.device)
         if t.dtype not in (torch.float32, torch.int32):
             raise TypeError('saga_amd ops take float32 / int32 tensors, got %s' % t.dtype)
+
+
+def profile_enable(on=True):
+    check(load().saga_profile_enable(1 if on else 0), 'saga_profile_enable')
+
+
+def profile_read():
+    """-> {kernel name: (total_ms, launches)} since the last read (synchronises the recorded events)."""
+    n = len(PROF_KERNELS)
+    ms = (ctypes.c_double * n)()
+    cnt = (ctypes.c_int32 * n)()
+    check(load().saga_profile_read(ms, cnt), 'saga_profile_read')
+    return {PROF_KERNELS[i]: (ms[i], cnt[i]) for i in range(n)}

@@ -10,6 +10,9 @@
 
 #include "saga_common.h"
 
+void* saga_prof_begin(int id, void* stream);
+void saga_prof_end(void* scope);
+
 #define NN_THREADS 256
 #define NN_TILE 1024
 
@@ -88,9 +91,11 @@ extern "C" int saga_chamfer_fwd(const float* x, const float* y, float* dist1, fl
     SAGA_CHECK_ARG(P1 > 0 && P2 > 0, "saga_chamfer_fwd: empty cloud (P1=%d, P2=%d) has no nearest neighbour", P1, P2);
     SAGA_CHECK_ARG(x && y, "saga_chamfer_fwd: null cloud");
     SAGA_CHECK_ARG(N <= 65535, "saga_chamfer_fwd: batch %d exceeds 65535", N);
+    void* prof = saga_prof_begin(SAGA_PROF_CHAMFER, stream);
     int rc = launch_scan(x, y, dist1, idx1, N, P1, P2, (hipStream_t)stream);
-    if (rc) return rc;
-    return launch_scan(y, x, dist2, idx2, N, P2, P1, (hipStream_t)stream);
+    if (!rc) rc = launch_scan(y, x, dist2, idx2, N, P2, P1, (hipStream_t)stream);
+    saga_prof_end(prof);
+    return rc;
 }
 
 // Backward of the two squared-distance outputs (the extension's NmDistanceGrad): for every point p of a with

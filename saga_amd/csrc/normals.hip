@@ -7,6 +7,9 @@
 
 #include "saga_common.h"
 
+void* saga_prof_begin(int id, void* stream);
+void saga_prof_end(void* scope);
+
 __global__ void vertex_normals_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces,
                                       const int32_t* __restrict__ vf_ptr, const int32_t* __restrict__ vf_idx,
                                       const int32_t* __restrict__ sel, int n_out, float* __restrict__ normals, int V) {
@@ -42,7 +45,9 @@ static int launch(const saga_model_t* m, const float* verts, const int32_t* sel,
     if (B == 0 || n_out == 0) return 0;
     SAGA_CHECK_ARG(verts && normals, "saga_vertex_normals: null argument");
     dim3 grid((n_out + 255) / 256, B);
+    void* prof = saga_prof_begin(SAGA_PROF_NORMALS, stream);
     vertex_normals_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(verts, m->faces, m->vf_ptr, m->vf_idx, sel, n_out, normals, m->V);
+    saga_prof_end(prof);
     SAGA_LAUNCH_CHECK();
     return 0;
 }

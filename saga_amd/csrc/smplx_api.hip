@@ -17,6 +17,56 @@ int saga_launch_joints_bwd(const saga_model* m, const float* g_joints, float* g_
 int saga_launch_skin_bwd(const saga_model* m, const float* A, const float* g_verts, const float* v_posed, float* g_vposed,
                          float* dA, int dA_stride, int B, hipStream_t st);
 
+// ---- optional per-kernel timing (HIP events on the launch stream) -------------------------------------------
+// bench.py turns this on for its timed region: every kernel launch of the path is bracketed by an event pair on
+// the stream it is launched on; saga_profile_read() resolves the pairs.  Off by default (zero overhead).
+#include <vector>
+struct ProfPair { hipEvent_t a, b; int id; };
+static bool g_prof_on = false;
+static std::vector<ProfPair> g_prof_pairs;
+static std::vector<ProfPair> g_prof_pool;
+
+struct ProfScope {
+    hipStream_t st; hipEvent_t b = nullptr; bool on;
+    ProfScope(int id, hipStream_t s) : st(s), on(g_prof_on) {
+        if (!on) return;
+        ProfPair p;
+        if (!g_prof_pool.empty()) { p = g_prof_pool.back(); g_prof_pool.pop_back(); }
+        else if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) { on = false; return; }
+        p.id = id;
+        (void)hipEventRecord(p.a, st);
+        b = p.b;
+        g_prof_pairs.push_back(p);
+    }
+    ~ProfScope() { if (on) (void)hipEventRecord(b, st); }
+};
+
+int saga_prof_is_on() { return g_prof_on; }
+void* saga_prof_begin(int id, void* stream) { return g_prof_on ? new ProfScope(id, (hipStream_t)stream) : nullptr; }
+void saga_prof_end(void* scope) { delete (ProfScope*)scope; }
+
+extern "C" int saga_profile_enable(int on) {
+    g_prof_on = on != 0;
+    return 0;
+}
+
+// Synchronises the recorded events; total_ms[id] += elapsed, count[id] += 1 for id in [0, SAGA_PROF_NKERNELS).
+extern "C" int saga_profile_read(double* total_ms_host, int32_t* count_host) {
+    SAGA_CHECK_ARG(total_ms_host && count_host, "saga_profile_read: null argument");
+    for (int i = 0; i < SAGA_PROF_NKERNELS; ++i) { total_ms_host[i] = 0.0; count_host[i] = 0; }
+    for (ProfPair& p : g_prof_pairs) {
+        SAGA_HIP(hipEventSynchronize(p.b));
+        float ms = 0.f;
+        SAGA_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+        if (p.id >= 0 && p.id < SAGA_PROF_NKERNELS) { total_ms_host[p.id] += ms; count_host[p.id] += 1; }
+        g_prof_pool.push_back(p);
+    }
+    g_prof_pairs.clear();
+    return 0;
+}
+
+#define PROF(id) ProfScope prof_scope_##id(id, st)
+
 extern "C" int saga_smplx_fwd(const saga_model_t* m, const float* shape, const float* full_pose, const float* transl,
                               float* vertices, float* joints, float* feat, float* rot, float* jrest, float* chain, float* A,
                               float* v_posed, int B, void* stream) {
@@ -27,10 +77,10 @@ extern "C" int saga_smplx_fwd(const saga_model_t* m, const float* shape, const f
                    "saga_smplx_fwd: null buffer");
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if ((rc = saga_launch_pose_fwd(m, shape, full_pose, feat, rot, jrest, chain, A, B, st))) return rc;
-    if ((rc = saga_launch_blend_fwd(m, feat, v_posed, B, st))) return rc;
-    if ((rc = saga_launch_skin_fwd(m, A, v_posed, transl, vertices, B, st))) return rc;
-    if (joints && (rc = saga_launch_joints_fwd(m, chain, vertices, transl, joints, B, st))) return rc;
+    { PROF(SAGA_PROF_POSE_FWD); if ((rc = saga_launch_pose_fwd(m, shape, full_pose, feat, rot, jrest, chain, A, B, st))) return rc; }
+    { PROF(SAGA_PROF_BLEND_FWD); if ((rc = saga_launch_blend_fwd(m, feat, v_posed, B, st))) return rc; }
+    { PROF(SAGA_PROF_SKIN_FWD); if ((rc = saga_launch_skin_fwd(m, A, v_posed, transl, vertices, B, st))) return rc; }
+    if (joints) { PROF(SAGA_PROF_JOINTS); if ((rc = saga_launch_joints_fwd(m, chain, vertices, transl, joints, B, st))) return rc; }
     return 0;
 }
 
@@ -66,13 +116,14 @@ extern "C" int saga_smplx_bwd(const saga_model_t* m, const float* g_vertices, co
             gv = ws_gv;
             has_verts = 1;
         }
-        if ((rc = saga_launch_joints_bwd(m, g_joints, g_pj, g_jsum, ws_gv, B, stride, st))) return rc;
+        { PROF(SAGA_PROF_JOINTS); if ((rc = saga_launch_joints_bwd(m, g_joints, g_pj, g_jsum, ws_gv, B, stride, st))) return rc; }
     }
     if (has_verts) {
         SAGA_CHECK_ARG(ws_gvp && ws_slab, "saga_smplx_bwd: workspace missing");
-        if ((rc = saga_launch_skin_bwd(m, A, gv, v_posed, ws_gvp, ws_dA, stride, B, st))) return rc;
-        if ((rc = saga_launch_blend_bwd(m, ws_gvp, ws_slab, B, st))) return rc;
+        { PROF(SAGA_PROF_SKIN_BWD); if ((rc = saga_launch_skin_bwd(m, A, gv, v_posed, ws_gvp, ws_dA, stride, B, st))) return rc; }
+        { PROF(SAGA_PROF_BLEND_BWD); if ((rc = saga_launch_blend_bwd(m, ws_gvp, ws_slab, B, st))) return rc; }
     }
+    PROF(SAGA_PROF_POSE_BWD);
     return saga_launch_pose_bwd(m, ws_dA, g_pj, g_jsum, ws_slab, SAGA_BWD_SPLITK, rot, jrest, chain, full_pose, g_shape, g_full_pose,
                                 g_transl, B, has_verts, st);
 }

@@ -18,6 +18,7 @@ import torch.optim as optim
 
 from . import smplx as _smplx
 from .geometry import point2point_signed, vertex_normals_subset
+from .grasp_loss import GraspTables, grasp_loss_terms
 from .rotations import RotConverter
 from .vposer import VPoserDecoder
 
@@ -51,7 +52,7 @@ class FittingOP:
         cfg = dict(init_lr_h=0.008, num_iter=[300, 400, 500], batch_size=1, num_markers=143, device='cuda',
                    verbose=False, hand_ncomps=24, only_rec=False, contact_loss='contact', logger=print,
                    data_type='markers_143', body_model_path='./body_utils/body_models', vposer=None, indices=None,
-                   smplx_kwargs={}, genders=('male', 'female'))
+                   smplx_kwargs={}, genders=('male', 'female'), fused=True)
         cfg.update(fittingconfig)
         for key, val in cfg.items():
             setattr(self, key, val)
@@ -96,6 +97,7 @@ class FittingOP:
         self.rhand_verts = torch.as_tensor(np.asarray(idx['rhand']), dtype=torch.long, device=dev)
         self.foot_markers_all = torch.as_tensor(np.asarray(idx['foot']), dtype=torch.long, device=dev)
         self.rhand_verts_i32 = self.rhand_verts.to(torch.int32)
+        self.tables = GraspTables(idx['markers_143'], idx['rhand'], idx['foot'], idx['rhand_weight'], dev)
 
     def _make_optimizers(self):
         lr = self.init_lr_h
@@ -143,14 +145,59 @@ class FittingOP:
     def calc_loss_contact_map(self, body_markers, verts_object, normal_object, contacts_object, contacts_markers,
                               gender, betas, stage, alpha):
         """fittingop.py:137-244 for B candidates.  ``loss`` and every ``loss_dict`` / ``vertices_info``
-        entry is a [B] device tensor (per-candidate values); call ``loss.sum().backward()``."""
+        entry is a [B] device tensor (per-candidate values); call ``loss.sum().backward()``.
+        Default: the fused HIP loss (``saga_grasp_loss_fwd/bwd``); ``fused=False`` in the config composes the
+        same loss from the drop-in operators the way the reference does (used to cross-check the fused path)."""
+        if not self.fused:
+            return self.calc_loss_contact_map_composed(body_markers, verts_object, normal_object, contacts_object,
+                                                       contacts_markers, gender, betas, stage, alpha)
+        B = self.batch_size
+        body_param = self.body_params()
+        output = self.bm(return_verts=True, **body_param)
+        r = grasp_loss_terms(output.vertices, self.bm, self.tables, verts_object.float(), normal_object.float(),
+                             body_markers, contacts_markers, contacts_object)
+        t = r['terms']
+        loss_rec, loss_body_rec, loss_foot = t[:, 0], t[:, 1], t[:, 2]
+        loss_marker_contact, loss_object_contact, loss_prior_contact = t[:, 3], t[:, 4], t[:, 5]
+        h_collision, loss_dist_o = t[:, 6], t[:, 7]
+        loss_vpose_reg = 0.0001 * (self.vpose_rec ** 2).mean(dim=1)
+        loss_hand_pose_reg = 0.0005 * (self.hand_pose ** 2).mean(dim=1)
+        loss_eye_pose_reg = 0.0001 * (self.eye_pose ** 2).mean(dim=1)
+        on = 0.0 if self.only_rec else 1.0
+        loss = (1 * loss_rec
+                + on * (self.contact_loss == 'contact') * (stage > 1) * 15 * (loss_marker_contact + loss_object_contact)
+                + on * (self.contact_loss == 'prior') * (stage > 1) * 15 * loss_prior_contact
+                + on * (stage > 1) * 10 * (h_collision + loss_dist_o)
+                + (stage > 1) * loss_hand_pose_reg
+                + (stage > 1) * loss_eye_pose_reg
+                + (stage > 0) * loss_vpose_reg
+                + 0.1 * loss_foot)
+        d = lambda x: x.detach()
+        loss_dict = {
+            'total': d(loss), 'rec': d(loss_rec), 'body_rec': d(loss_body_rec),
+            'marker contact': d(loss_marker_contact), 'object contact': d(loss_object_contact),
+            'prior contact': d(loss_prior_contact), 'hand collision': d(h_collision),
+            'object collision': d(loss_dist_o), 'foot': d(loss_foot),
+            'reg': d(loss_vpose_reg + loss_hand_pose_reg + loss_eye_pose_reg),
+        }
+        td = d(t)
+        vertices_info = {'hand colli': td[:, 8].long(), 'obj colli': td[:, 9].long(), 'contact': td[:, 10].long(),
+                         'hand markers colli': td[:, 11].long()}
+        return (loss, loss_dict, r['markers_rec'], body_param, vertices_info, r['hand_rec'], r['hand_normals'],
+                r['h2o_signed'], r['o2h_signed'])
+
+    def calc_loss_contact_map_composed(self, body_markers, verts_object, normal_object, contacts_object, contacts_markers,
+                                       gender, betas, stage, alpha):
+        """The same loss written the way the reference writes it, on the drop-in operators
+        (smplx forward, vertex normals, point2point_signed) + torch element-wise ops."""
         B = self.batch_size
         body_param = self.body_params()
         output = self.bm(return_verts=True, **body_param)
         verts_full = output.vertices
-        body_markers_rec = verts_full[:, self.markers_143, :]
-        foot_markers_rec = verts_full[:, self.foot_markers_all, :]
-        rhand_verts_rec = verts_full[:, self.rhand_verts, :]
+        # index_select (backward = index_add) instead of advanced indexing (backward = sorted index_put)
+        body_markers_rec = verts_full.index_select(1, self.markers_143)
+        foot_markers_rec = verts_full.index_select(1, self.foot_markers_all)
+        rhand_verts_rec = verts_full.index_select(1, self.rhand_verts)
         # vertex normals of the right hand, on the device, for every candidate (:158-164)
         rh_normals = vertex_normals_subset(self.bm, verts_full, self.rhand_verts_i32)
 

@@ -27,13 +27,13 @@ def point2point_signed(x, y, x_normals=None, y_normals=None, return_vector=False
     y2x = y - y_near
     if x_normals is not None:
         y_nn = x_normals.gather(1, yi)
-        in_out = torch.bmm(y_nn.view(-1, 1, 3), y2x.view(-1, 3, 1)).view(N, -1).sign()
+        in_out = (y_nn * y2x).detach().sum(-1).sign()     # only the sign is used (no gradient); a batched 1x3.3x1 bmm is 40 ms here
         y2x_signed = y2x.norm(dim=2) * in_out
     else:
         y2x_signed = y2x.norm(dim=2)
     if y_normals is not None:
         x_nn = y_normals.gather(1, xi)
-        in_out_x = torch.bmm(x_nn.view(-1, 1, 3), x2y.view(-1, 3, 1)).view(N, -1).sign()
+        in_out_x = (x_nn * x2y).detach().sum(-1).sign()
         x2y_signed = x2y.norm(dim=2) * in_out_x
     else:
         x2y_signed = x2y.norm(dim=2)

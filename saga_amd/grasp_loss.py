@@ -1,0 +1,104 @@
+"""Fused contact / penetration loss terms on the HIP kernels (``saga_grasp_loss_fwd/bwd``).
+
+One call replaces ``WholeGraspPose/models/fittingop.py:152-212`` for B independent candidates: marker /
+foot / right-hand gathers, hand vertex normals, both ``point2point_signed`` calls and the per-candidate
+means.  The returned ``terms`` tensor is differentiable w.r.t. ``verts``; the weighted sum over terms
+(stage gates, ``:215-223``) stays in Python on [B]-sized tensors.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+TERM_NAMES = ['rec', 'body_rec', 'foot', 'marker contact', 'object contact', 'prior contact', 'hand collision',
+              'object collision', 'hand colli', 'obj colli', 'contact', 'hand markers colli']
+
+
+class GraspTables:
+    """Device index tables of the loss (``fittingop.py:86-124``) + the struct handed to the C-ABI."""
+
+    def __init__(self, markers, hand, foot, hand_weights, device, n_body_markers=49):
+        markers, hand, foot = (np.asarray(a, dtype=np.int64) for a in (markers, hand, foot))
+        uniq = np.unique(np.concatenate([markers, hand, foot]))
+        slot = lambda ids: np.searchsorted(uniq, ids).astype(np.int32)
+        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=device)
+        self.marker_ids, self.hand_ids, self.foot_ids = i32(markers), i32(hand), i32(foot)
+        self.unique_ids = i32(uniq)
+        self.marker_slot, self.hand_slot, self.foot_slot = i32(slot(markers)), i32(slot(hand)), i32(slot(foot))
+        self.hand_weights = torch.as_tensor(np.asarray(hand_weights), dtype=torch.float32, device=device).contiguous()
+        self.n_markers, self.n_hand, self.n_foot, self.n_unique = len(markers), len(hand), len(foot), len(uniq)
+        self.max_id = int(uniq.max())
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        self.struct = _lib.GraspTables(
+            n_markers=self.n_markers, n_hand=self.n_hand, n_foot=self.n_foot,
+            n_body_markers=min(n_body_markers, self.n_markers), n_unique=self.n_unique,
+            marker_ids=p(self.marker_ids), hand_ids=p(self.hand_ids), foot_ids=p(self.foot_ids),
+            hand_weights=p(self.hand_weights), unique_ids=p(self.unique_ids), marker_slot=p(self.marker_slot),
+            hand_slot=p(self.hand_slot), foot_slot=p(self.foot_slot))
+
+
+class _GraspLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, model, tables, obj, obj_normals, markers_target, c_markers, c_object):
+        _lib.require_device(verts, obj, obj_normals, markers_target, c_markers, c_object)
+        lib = _lib.load()
+        B, V, _ = verts.shape
+        O = obj.shape[1]
+        if V != model.num_verts or tables.max_id >= V:
+            raise ValueError('vertex tables do not fit a mesh of %d vertices' % V)
+        if obj.shape != (B, O, 3) or obj_normals.shape != (B, O, 3) or markers_target.shape != (B, tables.n_markers, 3):
+            raise ValueError('grasp loss: inconsistent shapes')
+        c = lambda t: t.detach().contiguous()
+        verts_c, obj, obj_normals, markers_target = c(verts), c(obj), c(obj_normals), c(markers_target)
+        c_markers, c_object = c(c_markers).view(B, -1), c(c_object).view(B, -1)
+        dev = verts.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        i32 = dict(device=dev, dtype=torch.int32)
+        M, H = tables.n_markers, tables.n_hand
+        terms = torch.empty(B, _lib.GRASP_NTERMS, **f32)
+        markers_rec = torch.empty(B, M, 3, **f32)
+        hand_rec = torch.empty(B, H, 3, **f32)
+        hand_normals = torch.empty(B, H, 3, **f32)
+        h2o_marker = torch.empty(B, M, **f32)
+        h2o_signed = torch.empty(B, H, **f32)
+        o2h_signed = torch.empty(B, O, **f32)
+        idx_m2o = torch.empty(B, M, **i32)
+        idx_h2o = torch.empty(B, H, **i32)
+        idx_o2h = torch.empty(B, O, **i32)
+        P = _lib.ptr
+        _lib.check(lib.saga_grasp_loss_fwd(model.handle(dev), ctypes.byref(tables.struct), P(verts_c), P(obj), P(obj_normals),
+                                           P(markers_target), P(c_markers), P(c_object), P(terms), P(markers_rec), P(hand_rec),
+                                           P(hand_normals), P(h2o_marker), P(h2o_signed), P(o2h_signed), P(idx_m2o), P(idx_h2o),
+                                           P(idx_o2h), B, O, _lib.stream()), 'saga_grasp_loss_fwd')
+        ctx.model, ctx.tables = model, tables
+        ctx.save_for_backward(verts_c, obj, markers_target, c_markers, c_object, markers_rec, hand_rec, h2o_signed, o2h_signed,
+                              idx_m2o, idx_h2o, idx_o2h)
+        aux = (markers_rec, hand_rec, hand_normals, h2o_marker, h2o_signed, o2h_signed, idx_m2o, idx_h2o, idx_o2h)
+        ctx.mark_non_differentiable(*aux)
+        return (terms,) + aux
+
+    @staticmethod
+    def backward(ctx, g_terms, *_unused):
+        (verts, obj, markers_target, c_markers, c_object, markers_rec, hand_rec, h2o_signed, o2h_signed, idx_m2o, idx_h2o,
+         idx_o2h) = ctx.saved_tensors
+        lib = _lib.load()
+        B, V, _ = verts.shape
+        O = obj.shape[1]
+        g_terms = g_terms.contiguous()
+        g_verts = torch.empty_like(verts)
+        P = _lib.ptr
+        _lib.check(lib.saga_grasp_loss_bwd(ctx.model.handle(verts.device), ctypes.byref(ctx.tables.struct), P(g_terms), P(verts),
+                                           P(obj), P(markers_target), P(c_markers), P(c_object), P(markers_rec), P(hand_rec),
+                                           P(h2o_signed), P(o2h_signed), P(idx_m2o), P(idx_h2o), P(idx_o2h), P(g_verts), B, O,
+                                           _lib.stream()), 'saga_grasp_loss_bwd')
+        return g_verts, None, None, None, None, None, None, None
+
+
+def grasp_loss_terms(verts, model, tables, obj, obj_normals, markers_target, c_markers, c_object):
+    """-> dict with ``terms`` [B,16] (differentiable w.r.t. ``verts``) and the auxiliary outputs."""
+    out = _GraspLossFn.apply(verts, model, tables, obj, obj_normals, markers_target, c_markers, c_object)
+    keys = ['terms', 'markers_rec', 'hand_rec', 'hand_normals', 'h2o_marker', 'h2o_signed', 'o2h_signed', 'idx_m2o',
+            'idx_h2o', 'idx_o2h']
+    return dict(zip(keys, out))

@@ -14,12 +14,12 @@ pytestmark = pytest.mark.gpu
 LOSS_RTOL = 1e-4
 
 
-def _setup(body_model_dir, B, num_iter=(3, 3, 3), seed=1234, scale=0.3):
+def _setup(body_model_dir, B, num_iter=(3, 3, 3), seed=1234, scale=0.3, fused=True):
     from saga_amd.fitting import FittingOP, load_grasp_indices
     from saga_amd.vposer import VPoserDecoder
     vp = VPoserDecoder(seed=0)
     op = FittingOP({'batch_size': B, 'device': 'cuda', 'body_model_path': body_model_dir, 'vposer': vp,
-                    'genders': ('male',), 'num_iter': list(num_iter), 'verbose': False})
+                    'genders': ('male',), 'num_iter': list(num_iter), 'verbose': False, 'fused': fused})
     idx_np = load_grasp_indices()
     idx = {'markers_143': torch.from_numpy(idx_np['markers_143']), 'foot': torch.from_numpy(idx_np['foot']),
            'rhand': torch.from_numpy(idx_np['rhand']), 'v_weights': torch.from_numpy(idx_np['rhand_weight'])}
@@ -30,10 +30,11 @@ def _setup(body_model_dir, B, num_iter=(3, 3, 3), seed=1234, scale=0.3):
     return op, vp, idx, var_np, data
 
 
+@pytest.mark.parametrize('fused', [True, False])
 @pytest.mark.parametrize('stage', [0, 1, 2])
-def test_loss_and_gradients_match_oracle(body_model_dir, stage):
+def test_loss_and_gradients_match_oracle(body_model_dir, stage, fused):
     B = 3
-    op, vp, idx, var_np, d = _setup(body_model_dir, B)
+    op, vp, idx, var_np, d = _setup(body_model_dir, B, fused=fused)
     op.bm = op.bm_male
     op.set_variables(var_np)
     cu = lambda a: torch.from_numpy(a).cuda()
@@ -79,3 +80,23 @@ def test_short_fitting_trajectory_matches_oracle(body_model_dir):
         assert params[-1][k].shape[0] == B
         np.testing.assert_allclose(params[-1][k].cpu().numpy(), p_ref[-1][k].numpy(), atol=5e-3, err_msg=k)
     assert mfit[-1].shape == (B, 143, 3)
+
+
+def test_fused_outputs_match_composed_operators(body_model_dir):
+    """The fused kernel against the drop-in operators it replaces: identical NN indices, same signed distances."""
+    from saga_amd.geometry import point2point_signed, vertex_normals_subset
+    B = 4
+    op, vp, idx, var_np, d = _setup(body_model_dir, B)
+    op.bm = op.bm_male
+    op.set_variables(var_np)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    out = op.calc_loss_contact_map(cu(d['markers']), cu(d['verts_o']), cu(d['normals_o']), cu(d['oc']), cu(d['mc']), 'male', None, 2, 1.0)
+    loss, ld, mk, bp, info, rh, rn, h2o, o2h = out
+    with torch.no_grad():
+        verts = op.bm(return_verts=True, **op.body_params()).vertices
+        nrm = vertex_normals_subset(op.bm, verts, op.rhand_verts_i32)
+        o2h_c, h2o_c, _, _ = point2point_signed(verts[:, op.rhand_verts], cu(d['verts_o']), nrm, cu(d['normals_o']))
+    assert (nrm - rn).abs().max() < 1e-5
+    assert torch.equal(verts[:, op.rhand_verts], rh) and torch.equal(verts[:, op.markers_143], mk)
+    np.testing.assert_allclose(h2o.cpu().numpy(), h2o_c.cpu().numpy(), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(o2h.cpu().numpy(), o2h_c.cpu().numpy(), rtol=1e-5, atol=1e-8)
