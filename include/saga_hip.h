@@ -117,6 +117,14 @@ int saga_smplx_bwd(const saga_model_t* m, const float* g_vertices, const float* 
 int saga_rodrigues_fwd(const float* rot_vecs, float* rot_mats, int N, void* stream);
 int saga_rodrigues_bwd(const float* rot_vecs, const float* g_rot_mats, float* g_rot_vecs, int N, void* stream);
 
+/* 6D continuous rotation -> axis-angle in one pass: RotConverter.rotmat2aa(RotConverter.cont2rotmat(x))
+ * (utils/utils.py:385-417 -> :223-370), evaluated every iteration for the global orientation
+ * (WholeGraspPose/models/fittingop.py:140) and for VPoser's 21 decoded joints (:142).
+ *   x6 [N,6] -> aa [N,3] and jac [N,3,6] = d aa / d x6 (forward-mode, same branch as the value);
+ *   backward: g_x6 [N,6] = jac^T g_aa. */
+int saga_cont6d_to_aa_fwd(const float* x6, float* aa, float* jac, int N, void* stream);
+int saga_cont6d_to_aa_bwd(const float* jac, const float* g_aa, float* g_x6, int N, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * chamfer_distance.ChamferDistance(x, y) -> (dist1, dist2, idx1, idx2)
  * (reference call site utils/train_helper.py:57).  Brute-force bidirectional nearest

@@ -57,6 +57,8 @@ PROTOTYPES = {
     'saga_smplx_bwd': (ctypes.c_int, [ctypes.c_void_p] + [c_float_p] * 15 + [ctypes.c_int, c_stream]),
     'saga_rodrigues_fwd': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, c_stream]),
     'saga_rodrigues_bwd': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, ctypes.c_int, c_stream]),
+    'saga_cont6d_to_aa_fwd': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, ctypes.c_int, c_stream]),
+    'saga_cont6d_to_aa_bwd': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, ctypes.c_int, c_stream]),
     'saga_chamfer_fwd': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_int_p, c_int_p,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
     'saga_chamfer_bwd': (ctypes.c_int, [c_float_p, c_float_p, c_int_p, c_int_p, c_float_p, c_float_p,

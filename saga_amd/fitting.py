@@ -19,7 +19,7 @@ import torch.optim as optim
 from . import smplx as _smplx
 from .geometry import point2point_signed, vertex_normals_subset
 from .grasp_loss import GraspTables, grasp_loss_terms
-from .rotations import RotConverter
+from .rotations import RotConverter, cont6d_to_aa
 from .vposer import VPoserDecoder
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'grasp_indices.npz')
@@ -133,7 +133,7 @@ class FittingOP:
         B, n = self.batch_size, self.hand_ncomps
         return {
             'transl': self.transl_rec,
-            'global_orient': RotConverter.rotmat2aa(RotConverter.cont2rotmat(self.glo_rot_rec)),
+            'global_orient': cont6d_to_aa(self.glo_rot_rec),
             'betas': self.betas,
             'body_pose': self.vposer.decode(self.vpose_rec, output_type='aa').view(B, -1),
             'left_hand_pose': self.hand_pose[:, :n],
