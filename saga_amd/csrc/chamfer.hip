@@ -1,66 +1,51 @@
 // chamfer_distance.ChamferDistance(x, y) -> (dist1, dist2, idx1, idx2): brute-force bidirectional nearest neighbour.
 // Replaces the third-party CUDA extension called at utils/train_helper.py:57.
 //
-// Tiled scan: the "database" cloud is staged through LDS as float4 (x,y,z,-) tiles and read back with broadcast
-// ds_read_b128; each lane owns QPL query points in registers and keeps (best, index) per query with a strict '<',
-// candidates visited in index order, so the lowest index wins ties.  The squared distance is evaluated as
-// (dx*dx + dy*dy) + dz*dz with one rounding per operation (contraction off) -- the order the CPU oracle uses --
-// so indices are bit-exact against it.  FP32 VALU bound.
+// Tiled scan (nn_scan.h): the "database" cloud is staged through LDS in paired tiles and read back with broadcast
+// ds_read_b128; each lane owns NQ query points in registers; packed FP32 math, per-chunk minima and one re-scan of the
+// winning chunk give exactly the (best, index) of a sequential strict-'<' scan in index order (lowest index wins
+// ties).  Squared distance = fma(dz,dz, fma(dy,dy, dx*dx)), bit-exact against oracle/csrc/nn_ref.c.  FP32 VALU bound.
 #include <math.h>
 
 #include "saga_common.h"
+#include "nn_scan.h"
 
 void* saga_prof_begin(int id, void* stream);
 void saga_prof_end(void* scope);
 
-#define NN_THREADS 256
-#define NN_TILE 1024
+#define NN_TILE 2048
 
-template <int QPL>
-__global__ __launch_bounds__(NN_THREADS) void nn_scan_kernel(const float* __restrict__ q, const float* __restrict__ db,
-                                                             float* __restrict__ dist, int32_t* __restrict__ idx, int Pq,
-                                                             int Pd) {
-#pragma clang fp contract(off)
-    __shared__ float4 sdb[NN_TILE];
+template <int NQ, int NTH>
+__global__ __launch_bounds__(NTH) void nn_scan_kernel(const float* __restrict__ q, const float* __restrict__ db,
+                                                      float* __restrict__ dist, int32_t* __restrict__ idx, int Pq, int Pd) {
+    __shared__ __attribute__((aligned(16))) float sdb[NN_TILE_FLOATS(NN_TILE)];
     const int n = blockIdx.y;
     const int tid = threadIdx.x;
-    const int q0 = blockIdx.x * (NN_THREADS * QPL);
+    const int q0 = blockIdx.x * (NTH * NQ);
     const float* qn = q + (size_t)n * Pq * 3;
     const float* dn = db + (size_t)n * Pd * 3;
 
-    float qx[QPL], qy[QPL], qz[QPL], best[QPL];
-    int bi[QPL];
+    float qx[NQ], qy[NQ], qz[NQ], best[NQ];
+    int bc[NQ], bi[NQ];
 #pragma unroll
-    for (int i = 0; i < QPL; ++i) {
-        const int p = min(q0 + tid + i * NN_THREADS, Pq - 1);
+    for (int i = 0; i < NQ; ++i) {
+        const int p = min(q0 + tid + i * NTH, Pq - 1);
         qx[i] = qn[p * 3]; qy[i] = qn[p * 3 + 1]; qz[i] = qn[p * 3 + 2];
         best[i] = INFINITY;
+        bc[i] = -1;
         bi[i] = 0;
     }
     for (int t0 = 0; t0 < Pd; t0 += NN_TILE) {
         const int cnt = min(NN_TILE, Pd - t0);
+        if (t0) __syncthreads();
+        const int cnt_pad = nn_stage_tile(sdb, dn + (size_t)t0 * 3, cnt, tid, NTH);
         __syncthreads();
-        for (int k = tid; k < cnt; k += NN_THREADS) {
-            const float* p = dn + (size_t)(t0 + k) * 3;
-            sdb[k] = make_float4(p[0], p[1], p[2], 0.f);
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int k = 0; k < cnt; ++k) {
-            const float4 p = sdb[k];
-#pragma unroll
-            for (int i = 0; i < QPL; ++i) {
-                const float dx = qx[i] - p.x, dy = qy[i] - p.y, dz = qz[i] - p.z;
-                const float d = (dx * dx + dy * dy) + dz * dz;
-                const bool lt = d < best[i];
-                best[i] = lt ? d : best[i];
-                bi[i] = lt ? (t0 + k) : bi[i];
-            }
-        }
+        nn_scan_tile<NQ>(sdb, cnt_pad, t0, qx, qy, qz, best, bc);
+        nn_resolve_tile<NQ>(sdb, t0, qx, qy, qz, best, bc, bi);
     }
 #pragma unroll
-    for (int i = 0; i < QPL; ++i) {
-        const int p = q0 + tid + i * NN_THREADS;
+    for (int i = 0; i < NQ; ++i) {
+        const int p = q0 + tid + i * NTH;
         if (p < Pq) {
             if (dist) dist[(size_t)n * Pq + p] = best[i];
             if (idx) idx[(size_t)n * Pq + p] = bi[i];
@@ -70,15 +55,17 @@ __global__ __launch_bounds__(NN_THREADS) void nn_scan_kernel(const float* __rest
 
 static int launch_scan(const float* q, const float* db, float* dist, int32_t* idx, int N, int Pq, int Pd, hipStream_t st) {
     if (!dist && !idx) return 0;
-    if (Pq > NN_THREADS * 2) {
-        dim3 grid((Pq + NN_THREADS * 4 - 1) / (NN_THREADS * 4), N);
-        nn_scan_kernel<4><<<grid, NN_THREADS, 0, st>>>(q, db, dist, idx, Pq, Pd);
-    } else if (Pq > NN_THREADS) {
-        dim3 grid((Pq + NN_THREADS * 2 - 1) / (NN_THREADS * 2), N);
-        nn_scan_kernel<2><<<grid, NN_THREADS, 0, st>>>(q, db, dist, idx, Pq, Pd);
+    if (Pq <= 128) {
+        nn_scan_kernel<2, 64><<<dim3(1, N), 64, 0, st>>>(q, db, dist, idx, Pq, Pd);
+    } else if (Pq <= 256) {
+        nn_scan_kernel<2, 128><<<dim3(1, N), 128, 0, st>>>(q, db, dist, idx, Pq, Pd);
+    } else if (Pq <= 512) {
+        nn_scan_kernel<2, 256><<<dim3(1, N), 256, 0, st>>>(q, db, dist, idx, Pq, Pd);
+    } else if (Pq <= 1024) {
+        nn_scan_kernel<4, 256><<<dim3(1, N), 256, 0, st>>>(q, db, dist, idx, Pq, Pd);
     } else {
-        dim3 grid(1, N);
-        nn_scan_kernel<1><<<grid, NN_THREADS, 0, st>>>(q, db, dist, idx, Pq, Pd);
+        dim3 grid((Pq + 256 * 8 - 1) / (256 * 8), N);
+        nn_scan_kernel<8, 256><<<grid, 256, 0, st>>>(q, db, dist, idx, Pq, Pd);
     }
     SAGA_LAUNCH_CHECK();
     return 0;

@@ -13,29 +13,21 @@
 #include <math.h>
 
 #include "saga_common.h"
+#include "nn_scan.h"
 
 void* saga_prof_begin(int id, void* stream);
 void saga_prof_end(void* scope);
 
-#define GL_THREADS 512
+#define GL_THREADS 256          // forward: 4 waves; lanes own 4 queries (x->y) / 8 object points (y->x)
+#define GL_BWD_THREADS 512
 #define GL_TILE 2048            // object points staged per LDS tile
 #define GL_MAX_HAND 1024
 #define GL_MAX_MARK 256
 #define GL_MAX_UNIQUE 2048
+#define GL_NQ 4                 // queries per lane, hand/marker -> object  (4 * 256 = 1024 queries)
+#define GL_NO 8                 // object points per lane, object -> hand   (8 * 256 = 2048 points per pass)
+#define GL_NSUM 12
 #define NT SAGA_GRASP_NTERMS
-
-__device__ __forceinline__ float block_sum(float v, float* red) {
-    // all GL_THREADS threads call; returns the total in every thread
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < GL_THREADS / 64; ++w) s += red[w];
-    return s;
-}
 
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 
@@ -48,24 +40,39 @@ __global__ __launch_bounds__(GL_THREADS) void grasp_loss_fwd_kernel(
     float* __restrict__ h2o_signed, float* __restrict__ o2h_signed, int32_t* __restrict__ idx_m2o,
     int32_t* __restrict__ idx_h2o, int32_t* __restrict__ idx_o2h, int V, int O) {
 #pragma clang fp contract(off)
-    __shared__ float4 sObj[GL_TILE];
-    __shared__ float4 sQ[GL_MAX_HAND + GL_MAX_MARK];     // hand vertices first, then markers
-    __shared__ float4 sNrm[GL_MAX_HAND];
-    __shared__ float red[GL_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) float sObj[NN_TILE_FLOATS(GL_TILE)];        // paired layout (nn_scan.h)
+    __shared__ __attribute__((aligned(16))) float sHand[NN_TILE_FLOATS(GL_MAX_HAND)];   // hand vertices, paired + padded
+    __shared__ float sNrm[GL_MAX_HAND * 3];
+    __shared__ float red[GL_THREADS / 64][GL_NSUM];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int H = tb.n_hand, M = tb.n_markers, NQ = H + M;
+    const int Hpad = (H + NN_CH - 1) / NN_CH * NN_CH;
     const float* vb = verts + (size_t)b * V * 3;
     const float* ob = obj + (size_t)b * O * 3;
     const float* onb = obj_n + (size_t)b * O * 3;
 
-    // ---- gather hand vertices + markers; hand normals (area-weighted, ascending face order) ----------------
-    for (int i = tid; i < NQ; i += GL_THREADS) {
-        const int v = i < H ? tb.hand_ids[i] : tb.marker_ids[i - H];
-        const float x = vb[v * 3], y = vb[v * 3 + 1], z = vb[v * 3 + 2];
-        sQ[i] = make_float4(x, y, z, 0.f);
-        float* dst = i < H ? hand_rec + ((size_t)b * H + i) * 3 : markers_rec + ((size_t)b * M + (i - H)) * 3;
-        dst[0] = x; dst[1] = y; dst[2] = z;
+    // ---- x -> y queries: lane owns hand vertices / markers q = tid + i*GL_THREADS, i < GL_NQ ------------------
+    float qx[GL_NQ], qy[GL_NQ], qz[GL_NQ];
+#pragma unroll
+    for (int i = 0; i < GL_NQ; ++i) {
+        const int q = tid + i * GL_THREADS;
+        const int qc = min(q, NQ - 1);
+        const int v = qc < H ? tb.hand_ids[qc] : tb.marker_ids[qc - H];
+        qx[i] = vb[v * 3]; qy[i] = vb[v * 3 + 1]; qz[i] = vb[v * 3 + 2];
+        if (q < NQ) {
+            float* dst = q < H ? hand_rec + ((size_t)b * H + q) * 3 : markers_rec + ((size_t)b * M + (q - H)) * 3;
+            dst[0] = qx[i]; dst[1] = qy[i]; dst[2] = qz[i];
+            if (q < H) {
+                float* d = sHand + (q >> 1) * 6 + (q & 1);
+                d[0] = qx[i]; d[2] = qy[i]; d[4] = qz[i];
+            }
+        }
     }
+    for (int q = H + tid; q < Hpad; q += GL_THREADS) {
+        float* d = sHand + (q >> 1) * 6 + (q & 1);
+        d[0] = NN_FAR; d[2] = NN_FAR; d[4] = NN_FAR;
+    }
+    // ---- hand normals (area-weighted, ascending face order) --------------------------------------------------
     for (int i = tid; i < H; i += GL_THREADS) {
         const int v = tb.hand_ids[i];
         float nx = 0.f, ny = 0.f, nz = 0.f;
@@ -81,144 +88,130 @@ __global__ __launch_bounds__(GL_THREADS) void grasp_loss_fwd_kernel(
         const float sq = nx * nx + ny * ny + nz * nz;
         if (sq > 0.f) { const float inv = 1.0f / sqrtf(sq); nx *= inv; ny *= inv; nz *= inv; }
         if (isnan(nx)) { nx = 0.f; ny = 0.f; nz = 1.f; }
-        sNrm[i] = make_float4(nx, ny, nz, 0.f);
+        sNrm[i * 3] = nx; sNrm[i * 3 + 1] = ny; sNrm[i * 3 + 2] = nz;
         float* dst = hand_normals + ((size_t)b * H + i) * 3;
         dst[0] = nx; dst[1] = ny; dst[2] = nz;
     }
 
+    float sums[GL_NSUM];
+#pragma unroll
+    for (int i = 0; i < GL_NSUM; ++i) sums[i] = 0.f;
+    // sums: 0 rec 1 body_rec 2 foot 3 marker contact 4 object contact 5 prior 6 hand colli 7 obj colli
+    //       8 n hand colli 9 n obj colli 10 n contact 11 n marker colli
+
     // ---- x -> y : every hand vertex / marker finds its nearest object point -------------------------------
-    float qx[2], qy[2], qz[2], best[2];
-    int bi[2];
-    __syncthreads();
+    {
+        float best[GL_NQ];
+        int bc[GL_NQ], bi[GL_NQ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int q = min(tid + i * GL_THREADS, NQ - 1);
-        qx[i] = sQ[q].x; qy[i] = sQ[q].y; qz[i] = sQ[q].z;
-        best[i] = INFINITY; bi[i] = 0;
-    }
-    for (int t0 = 0; t0 < O; t0 += GL_TILE) {
-        const int cnt = min(GL_TILE, O - t0);
-        __syncthreads();
-        for (int k = tid; k < cnt; k += GL_THREADS) {
-            const float* p = ob + (size_t)(t0 + k) * 3;
-            sObj[k] = make_float4(p[0], p[1], p[2], 0.f);
+        for (int i = 0; i < GL_NQ; ++i) { best[i] = INFINITY; bc[i] = -1; bi[i] = 0; }
+        for (int t0 = 0; t0 < O; t0 += GL_TILE) {
+            const int cnt = min(GL_TILE, O - t0);
+            if (t0) __syncthreads();
+            const int cnt_pad = nn_stage_tile(sObj, ob + (size_t)t0 * 3, cnt, tid, GL_THREADS);
+            __syncthreads();                 // also publishes sHand / sNrm on the first pass
+            nn_scan_tile<GL_NQ>(sObj, cnt_pad, t0, qx, qy, qz, best, bc);
+            nn_resolve_tile<GL_NQ>(sObj, t0, qx, qy, qz, best, bc, bi);
         }
-        __syncthreads();
-#pragma unroll 4
-        for (int k = 0; k < cnt; ++k) {
-            const float4 p = sObj[k];
+        // per-query terms
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float dx = qx[i] - p.x, dy = qy[i] - p.y, dz = qz[i] - p.z;
-                const float d = (dx * dx + dy * dy) + dz * dz;
-                const bool lt = d < best[i];
-                best[i] = lt ? d : best[i];
-                bi[i] = lt ? (t0 + k) : bi[i];
+        for (int i = 0; i < GL_NQ; ++i) {
+            const int q = tid + i * GL_THREADS;
+            if (q >= NQ) continue;
+            const float x = qx[i], y = qy[i], z = qz[i];
+            const int k = bi[i];
+            const float dx = x - ob[k * 3], dy = y - ob[k * 3 + 1], dz = z - ob[k * 3 + 2];
+            const float dist = sqrtf((dx * dx + dy * dy) + dz * dz);
+            if (q < H) {
+                // h2o_signed: sign from the OBJECT normal at the neighbour (train_helper.py:76-79)
+                const float dot = (onb[k * 3] * dx + onb[k * 3 + 1] * dy) + onb[k * 3 + 2] * dz;
+                const float d = dist * sgn(dot);
+                h2o_signed[(size_t)b * H + q] = d;
+                idx_h2o[(size_t)b * H + q] = k;
+                const float vw = tb.hand_weights[q];
+                const bool near = (d < 0.02f) && (d > 0.f) && (powf(vw, 1.0f / 2.5f) > 0.7f);   // fittingop.py:195
+                sums[5] += fabsf(d) * (near ? vw : 0.f);                                          // :199,210
+                sums[6] += fabsf(d) * (d < 0.f ? 10.f : 0.f);                                     // :200,211
+                sums[8] += d < 0.f ? 1.f : 0.f;
+                sums[10] += (d < 0.001f && d > -0.001f) ? 1.f : 0.f;
+            } else {
+                const int p = q - H;
+                // marker call (:183): y_normals is None -> unsigned distance
+                h2o_marker[(size_t)b * M + p] = dist;
+                idx_m2o[(size_t)b * M + p] = k;
+                sums[3] += dist * c_mk[(size_t)b * M + p];                                        // :190
+                const float* tg = mk_target + ((size_t)b * M + p) * 3;
+                const float e = (fabsf(x - tg[0]) + fabsf(y - tg[1])) + fabsf(z - tg[2]);
+                sums[0] += e;                                                                     // :168
+                if (p < tb.n_body_markers) sums[1] += e;                                          // :169
+                sums[11] += dist < 0.f ? 1.f : 0.f;
             }
-        }
-    }
-    // per-query terms
-    float t_rec = 0.f, t_brec = 0.f, t_mc = 0.f, t_prior = 0.f, t_hcol = 0.f;
-    float n_hcol = 0.f, n_contact = 0.f, n_mcol = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int q = tid + i * GL_THREADS;
-        if (q >= NQ) continue;
-        const int k = bi[i];
-        const float dx = qx[i] - ob[k * 3], dy = qy[i] - ob[k * 3 + 1], dz = qz[i] - ob[k * 3 + 2];
-        const float dist = sqrtf((dx * dx + dy * dy) + dz * dz);
-        if (q < H) {
-            // h2o_signed: sign from the OBJECT normal at the neighbour (train_helper.py:76-79)
-            const float dot = (onb[k * 3] * dx + onb[k * 3 + 1] * dy) + onb[k * 3 + 2] * dz;
-            const float d = dist * sgn(dot);
-            h2o_signed[(size_t)b * H + q] = d;
-            idx_h2o[(size_t)b * H + q] = k;
-            const float vw = tb.hand_weights[q];
-            const bool near = (d < 0.02f) && (d > 0.f) && (powf(vw, 1.0f / 2.5f) > 0.7f);   // fittingop.py:195
-            t_prior += fabsf(d) * (near ? vw : 0.f);                                         // :199,210
-            t_hcol += fabsf(d) * (d < 0.f ? 10.f : 0.f);                                     // :200,211
-            n_hcol += d < 0.f ? 1.f : 0.f;
-            n_contact += (d < 0.001f && d > -0.001f) ? 1.f : 0.f;
-        } else {
-            const int p = q - H;
-            // marker call (:183): y_normals is None -> unsigned distance
-            h2o_marker[(size_t)b * M + p] = dist;
-            idx_m2o[(size_t)b * M + p] = k;
-            t_mc += dist * c_mk[(size_t)b * M + p];                                          // :190
-            const float* tg = mk_target + ((size_t)b * M + p) * 3;
-            const float e = (fabsf(qx[i] - tg[0]) + fabsf(qy[i] - tg[1])) + fabsf(qz[i] - tg[2]);
-            t_rec += e;                                                                       // :168
-            if (p < tb.n_body_markers) t_brec += e;                                           // :169
-            n_mcol += dist < 0.f ? 1.f : 0.f;
         }
     }
     // foot term: 0.1 * mean |z| (:173)
-    float t_foot = 0.f;
-    for (int i = tid; i < tb.n_foot; i += GL_THREADS) t_foot += fabsf(vb[tb.foot_ids[i] * 3 + 2]);
+    for (int i = tid; i < tb.n_foot; i += GL_THREADS) sums[2] += fabsf(vb[tb.foot_ids[i] * 3 + 2]);
 
     // ---- y -> x : every object point finds its nearest HAND vertex (the marker direction is never used) ------
-    float t_oc = 0.f, t_ocol = 0.f, n_ocol = 0.f;
-    for (int k0 = 0; k0 < O; k0 += GL_THREADS * 4) {
-        float ox[4], oy[4], oz[4], ob_best[4];
-        int oj[4];
+    // the hand cloud sHand[0 .. Hpad) is the (single) database tile; lane owns object points k0 + tid + i*GL_THREADS
+    for (int k0 = 0; k0 < O; k0 += GL_THREADS * GL_NO) {
+        float ox[GL_NO], oy[GL_NO], oz[GL_NO], best[GL_NO];
+        int bc[GL_NO], bj[GL_NO];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < GL_NO; ++i) {
             const int k = min(k0 + tid + i * GL_THREADS, O - 1);
             ox[i] = ob[k * 3]; oy[i] = ob[k * 3 + 1]; oz[i] = ob[k * 3 + 2];
-            ob_best[i] = INFINITY; oj[i] = 0;
+            best[i] = INFINITY; bc[i] = -1; bj[i] = 0;
         }
-#pragma unroll 2
-        for (int j = 0; j < H; ++j) {
-            const float4 p = sQ[j];
+        nn_scan_tile<GL_NO>(sHand, Hpad, 0, ox, oy, oz, best, bc);
+        nn_resolve_tile<GL_NO>(sHand, 0, ox, oy, oz, best, bc, bj);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float dx = ox[i] - p.x, dy = oy[i] - p.y, dz = oz[i] - p.z;
-                const float d = (dx * dx + dy * dy) + dz * dz;
-                const bool lt = d < ob_best[i];
-                ob_best[i] = lt ? d : ob_best[i];
-                oj[i] = lt ? j : oj[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < GL_NO; ++i) {
             const int k = k0 + tid + i * GL_THREADS;
             if (k >= O) continue;
-            const int j = oj[i];
-            const float dx = ox[i] - sQ[j].x, dy = oy[i] - sQ[j].y, dz = oz[i] - sQ[j].z;
+            const int j = bj[i];
+            float hx, hy, hz;
+            nn_tile_point(sHand, j, hx, hy, hz);
+            const float dx = ox[i] - hx, dy = oy[i] - hy, dz = oz[i] - hz;
             const float dist = sqrtf((dx * dx + dy * dy) + dz * dz);
-            const float dot = (sNrm[j].x * dx + sNrm[j].y * dy) + sNrm[j].z * dz;           // HAND normal (:68-71)
+            const float dot = (sNrm[j * 3] * dx + sNrm[j * 3 + 1] * dy) + sNrm[j * 3 + 2] * dz;   // HAND normal (:68-71)
             const float d = dist * sgn(dot);
             o2h_signed[(size_t)b * O + k] = d;
             idx_o2h[(size_t)b * O + k] = j;
-            t_oc += fabsf(d) * c_obj[(size_t)b * O + k];                                      // :191
-            t_ocol += fabsf(d) * (d < 0.f ? 20.f : 0.f);                                      // :206,212
-            n_ocol += d < 0.f ? 1.f : 0.f;
+            sums[4] += fabsf(d) * c_obj[(size_t)b * O + k];                                  // :191
+            sums[7] += fabsf(d) * (d < 0.f ? 20.f : 0.f);                                    // :206,212
+            sums[9] += d < 0.f ? 1.f : 0.f;
         }
     }
 
-    // ---- per-candidate means ---------------------------------------------------------------------------------
-    const float s_rec = block_sum(t_rec, red), s_brec = block_sum(t_brec, red), s_foot = block_sum(t_foot, red);
-    const float s_mc = block_sum(t_mc, red), s_oc = block_sum(t_oc, red), s_prior = block_sum(t_prior, red);
-    const float s_hcol = block_sum(t_hcol, red), s_ocol = block_sum(t_ocol, red);
-    const float c_hcol = block_sum(n_hcol, red), c_ocol = block_sum(n_ocol, red), c_cont = block_sum(n_contact, red);
-    const float c_mcol = block_sum(n_mcol, red);
+    // ---- per-candidate means: wave shuffles, then the four wave partials in wave order ---------------------
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int i = 0; i < GL_NSUM; ++i) {
+        float v = sums[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
     if (tid == 0) {
+        float sm[GL_NSUM];
+#pragma unroll
+        for (int i = 0; i < GL_NSUM; ++i) sm[i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
         float* t = terms + (size_t)b * NT;
-        t[0] = s_rec / (float)(M * 3);
-        t[1] = s_brec / (float)(tb.n_body_markers * 3);
-        t[2] = 0.1f * (s_foot / (float)tb.n_foot);
-        t[3] = s_mc / (float)M;
-        t[4] = s_oc / (float)O;
-        t[5] = s_prior / (float)H;
-        t[6] = s_hcol / (float)H;
-        t[7] = s_ocol / (float)O;
-        t[8] = c_hcol; t[9] = c_ocol; t[10] = c_cont; t[11] = c_mcol;
+        t[0] = sm[0] / (float)(M * 3);
+        t[1] = sm[1] / (float)(tb.n_body_markers * 3);
+        t[2] = 0.1f * (sm[2] / (float)tb.n_foot);
+        t[3] = sm[3] / (float)M;
+        t[4] = sm[4] / (float)O;
+        t[5] = sm[5] / (float)H;
+        t[6] = sm[6] / (float)H;
+        t[7] = sm[7] / (float)O;
+        t[8] = sm[8]; t[9] = sm[9]; t[10] = sm[10]; t[11] = sm[11];
         t[12] = 0.f; t[13] = 0.f; t[14] = 0.f; t[15] = 0.f;
     }
 }
 
 // grad_vertices [B,V,3] (pre-zeroed) from the upstream gradients of the eight differentiable terms
-__global__ __launch_bounds__(GL_THREADS) void grasp_loss_bwd_kernel(
+__global__ __launch_bounds__(GL_BWD_THREADS) void grasp_loss_bwd_kernel(
     saga_grasp_tables_t tb, const float* __restrict__ g_terms, const float* __restrict__ verts,
     const float* __restrict__ obj, const float* __restrict__ mk_target, const float* __restrict__ c_mk,
     const float* __restrict__ c_obj, const float* __restrict__ markers_rec, const float* __restrict__ hand_rec,
@@ -232,10 +225,10 @@ __global__ __launch_bounds__(GL_THREADS) void grasp_loss_bwd_kernel(
                 g_ocol = gt[7];
     const float* vb = verts + (size_t)b * V * 3;
     const float* ob = obj + (size_t)b * O * 3;
-    for (int i = tid; i < U * 3; i += GL_THREADS) acc[i] = 0.f;
+    for (int i = tid; i < U * 3; i += GL_BWD_THREADS) acc[i] = 0.f;
     __syncthreads();
     // markers: L1 reconstruction + contact-weighted distance to the nearest object point
-    for (int p = tid; p < M; p += GL_THREADS) {
+    for (int p = tid; p < M; p += GL_BWD_THREADS) {
         const float* m = markers_rec + ((size_t)b * M + p) * 3;
         const float* tg = mk_target + ((size_t)b * M + p) * 3;
         const int k = idx_m2o[(size_t)b * M + p];
@@ -249,12 +242,12 @@ __global__ __launch_bounds__(GL_THREADS) void grasp_loss_bwd_kernel(
         atomicAdd(a + 2, wr * sgn(m[2] - tg[2]) + w * dz);
     }
     // foot: 0.1 * mean |z|
-    for (int f = tid; f < tb.n_foot; f += GL_THREADS) {
+    for (int f = tid; f < tb.n_foot; f += GL_BWD_THREADS) {
         const float z = vb[tb.foot_ids[f] * 3 + 2];
         atomicAdd(acc + tb.foot_slot[f] * 3 + 2, g_foot * 0.1f * sgn(z) / (float)tb.n_foot);
     }
     // hand -> object: |d_h| weighted by the prior-contact / collision masks (masks carry no gradient)
-    for (int p = tid; p < H; p += GL_THREADS) {
+    for (int p = tid; p < H; p += GL_BWD_THREADS) {
         const float d = h2o_signed[(size_t)b * H + p];
         const float vw = tb.hand_weights[p];
         const bool near = (d < 0.02f) && (d > 0.f) && (powf(vw, 1.0f / 2.5f) > 0.7f);
@@ -270,7 +263,7 @@ __global__ __launch_bounds__(GL_THREADS) void grasp_loss_bwd_kernel(
         }
     }
     // object -> hand: gradient lands on the nearest hand vertex (scatter-add; many object points share one vertex)
-    for (int k = tid; k < O; k += GL_THREADS) {
+    for (int k = tid; k < O; k += GL_BWD_THREADS) {
         const float d = o2h_signed[(size_t)b * O + k];
         const float coef = (g_oc * c_obj[(size_t)b * O + k] + g_ocol * (d < 0.f ? 20.f : 0.f)) / (float)O;
         if (coef != 0.f && d != 0.f) {
@@ -284,13 +277,13 @@ __global__ __launch_bounds__(GL_THREADS) void grasp_loss_bwd_kernel(
     }
     __syncthreads();
     float* gb = g_verts + (size_t)b * V * 3;
-    for (int i = tid; i < U * 3; i += GL_THREADS) gb[tb.unique_ids[i / 3] * 3 + (i % 3)] = acc[i];
+    for (int i = tid; i < U * 3; i += GL_BWD_THREADS) gb[tb.unique_ids[i / 3] * 3 + (i % 3)] = acc[i];
 }
 
 static int check_tables(const saga_grasp_tables_t* tb) {
     SAGA_CHECK_ARG(tb, "grasp loss: null tables");
     SAGA_CHECK_ARG(tb->n_hand > 0 && tb->n_hand <= GL_MAX_HAND && tb->n_markers > 0 && tb->n_markers <= GL_MAX_MARK &&
-                       tb->n_hand + tb->n_markers <= 2 * GL_THREADS,
+                       tb->n_hand + tb->n_markers <= GL_NQ * GL_THREADS,
                    "grasp loss: n_hand=%d (max %d), n_markers=%d (max %d)", tb->n_hand, GL_MAX_HAND, tb->n_markers, GL_MAX_MARK);
     SAGA_CHECK_ARG(tb->n_foot > 0 && tb->n_unique > 0 && tb->n_unique <= GL_MAX_UNIQUE && tb->n_body_markers > 0 &&
                        tb->n_body_markers <= tb->n_markers,
@@ -341,7 +334,7 @@ extern "C" int saga_grasp_loss_bwd(const saga_model_t* m, const saga_grasp_table
     void* prof = saga_prof_begin(SAGA_PROF_GRASP_BWD, stream);
     hipError_t e = hipMemsetAsync(g_verts, 0, (size_t)B * m->V * 3 * sizeof(float), st);
     if (e == hipSuccess)
-        grasp_loss_bwd_kernel<<<B, GL_THREADS, 0, st>>>(*tb, g_terms, verts, obj, markers_target, c_markers, c_object, markers_rec,
+        grasp_loss_bwd_kernel<<<B, GL_BWD_THREADS, 0, st>>>(*tb, g_terms, verts, obj, markers_target, c_markers, c_object, markers_rec,
                                                         hand_rec, h2o_signed, o2h_signed, idx_m2o, idx_h2o, idx_o2h, g_verts, m->V, O);
     saga_prof_end(prof);
     SAGA_HIP(e);

@@ -64,18 +64,33 @@ def test_point2point_signed_shape_error():
         geometry_ref.point2point_signed(torch.zeros(2, 5, 3), torch.zeros(3, 7, 3))
 
 
-def test_chamfer_vectorised_equals_literal_scan():
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_chamfer_c_scan_equals_literal_definition(dtype):
+    """oracle/csrc/nn_ref.c (fmaf chain) against the exact-arithmetic literal scan, bit for bit."""
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(2, 37, 3, generator=g)
-    y = torch.randn(2, 53, 3, generator=g)
+    x = torch.randn(2, 37, 3, generator=g).to(dtype)
+    y = torch.randn(2, 53, 3, generator=g).to(dtype)
     y[0, 10] = y[0, 3]                      # exact tie: lowest index must win
     x[1, 5] = x[1, 2]
-    d1, d2, i1, i2 = chamfer_ref.chamfer_distance(x, y, chunk=16)
+    d1, d2, i1, i2 = chamfer_ref.chamfer_distance(x, y)
     l1, l2, li1, li2 = chamfer_ref.chamfer_distance_loop(x.numpy(), y.numpy())
     assert np.array_equal(i1.numpy(), li1) and np.array_equal(i2.numpy(), li2)
     assert np.array_equal(d1.numpy(), l1) and np.array_equal(d2.numpy(), l2)
     assert not (i1[0] == 10).any()
     assert not (i2[1] == 5).any()
+    assert d1.dtype == dtype and i1.dtype == torch.int32
+
+
+def test_chamfer_fma_chain_differs_from_unfused_sum_only_in_last_ulp():
+    """The contraction is part of the definition: it moves squared distances by at most 1 ulp."""
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 64, 3, generator=g)
+    y = torch.randn(1, 512, 3, generator=g)
+    d1, _, i1, _ = chamfer_ref.chamfer_distance(x, y)
+    d = x[:, :, None, :] - y[:, None, :, :]
+    un = ((d * d)[..., 0] + (d * d)[..., 1]) + (d * d)[..., 2]
+    m = un.min(dim=2).values
+    assert (d1 - m).abs().max() <= 2 * torch.finfo(torch.float32).eps * m.max()
 
 
 def _small_model(dtype=torch.float64, **kw):
