@@ -1,10 +1,12 @@
 // FP32-MFMA "NT" GEMM for the blend-shape contraction of SMPL-X (the dominant kernel of the path):
 //   forward : v_posed[B, Npad]  = v_template + feat[B,512] . Bt[Npad,512]^T      (shape + pose blend shapes, K = 20+486 -> 512)
 //   backward: g_feat[B, 512]    = g_v_posed[B,Npad] . Bk[512,Npad]^T              (split-K slabs, summed by pose_bwd_kernel)
-// Both operands are stored with the contraction index contiguous, so global loads are 16 B/lane and the
-// LDS image is [row][k] read back with ds_read_b128.  v_mfma_f32_32x32x2_f32 is an exact f32 FMA chain
-// (no xf32 on gfx950): lanes 0-31 supply k = 8g+t, lanes 32-63 k = 8g+4+t for MFMA t of k-group g -- any
-// k permutation is valid as long as A and B agree.
+// Both operands are stored with the contraction index contiguous.  Staging is LDS-DMA (global_load_lds_dwordx4: no
+// staging VGPRs, no ds_write): one wave-instruction moves 8 rows x 128 B into a lane-linear [128 rows][8 x 16 B] image;
+// the bank-conflict swizzle (16-B slot ^= (row>>1)&7) is applied on the per-lane SOURCE address and again on the
+// ds_read_b128 address.  Two LDS stages, tile t+1 in flight while tile t is multiplied, one barrier per k-tile.
+// v_mfma_f32_32x32x2_f32 is an exact f32 FMA chain (no xf32 on gfx950): lanes 0-31 supply k = 8g+t, lanes 32-63
+// k = 8g+4+t for MFMA t of k-group g -- any k permutation is valid as long as A and B agree.
 // Replaces smplx.lbs.blend_shapes + the posedirs matmul.
 #include "saga_common.h"
 
@@ -13,18 +15,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define BM 128
 #define BN 128
 #define BK 32
-#define LDS_LD (BK + 4)   // 36 floats: conflict-free ds_read_b128 over the 16-lane groups
+#define TILE_FLOATS (BM * BK)   // one operand tile: 128 rows x 32 floats = 16 KiB, 16 LDS-DMA pieces of 1 KiB
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 // EPI 0: C[row][col] = acc + bias[col]           (C row stride ldc)
 // EPI 1: C[z][row][col] = acc                    (slab z = blockIdx.z, slab stride M*ldc)
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const float* __restrict__ A, int lda,
-                                                             const float* __restrict__ Bt, int ldb,
-                                                             float* __restrict__ C, int ldc,
-                                                             const float* __restrict__ bias, int M, int N, int K,
-                                                             int kchunk, int tiles_m) {
-    __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
+__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ Bt, int ldb, float* __restrict__ C,
+                                                          int ldc, const float* __restrict__ bias, int M, int N, int K,
+                                                          int kchunk, int tiles_m) {
+    // ONE shared array (a second LDS object beside an LDS-DMA target makes hipcc drain vmcnt before every ds_read)
+    __shared__ __attribute__((aligned(1024))) float smem[2 * 2 * TILE_FLOATS];   // [stage][A|B][128][32]
 
     // consecutive blocks walk M first so the (large, batch-shared) Bt tile stays hot in L2 while A is re-read
     const int tile_m = blockIdx.x % tiles_m;
@@ -32,23 +36,33 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const float* __rest
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int k_begin = blockIdx.z * kchunk;
     const int k_end = min(K, k_begin + kchunk);
+    const int T = (k_end - k_begin) / BK;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
 
-    // global -> register staging: thread covers rows (tid>>3) + 32*i, float4 column (tid&7)
-    const int ld_row = tid >> 3, ld_c4 = (tid & 7) * 4;
-    const float* a_ptr[4];
-    const float* b_ptr[4];
+    // LDS-DMA source addresses: piece p = wave*4 + j covers tile rows 8p .. 8p+7; lane -> (row 8p + lane>>3, slot lane&7)
+    // and fetches the 16-B k-chunk slot ^ ((row>>1)&7) of that row.
+    const float* a_src[4];
+    const float* b_src[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ra = min(m0 + ld_row + 32 * i, M - 1);
-        const int rb = min(n0 + ld_row + 32 * i, N - 1);
-        a_ptr[i] = A + (size_t)ra * lda + ld_c4;
-        b_ptr[i] = Bt + (size_t)rb * ldb + ld_c4;
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        a_src[j] = A + (size_t)min(m0 + row, M - 1) * lda + k_begin + chunk * 4;
+        b_src[j] = Bt + (size_t)min(n0 + row, N - 1) * ldb + k_begin + chunk * 4;
     }
+    auto issue = [&](int stage, int koff) {
+        float* sa = smem + stage * (2 * TILE_FLOATS) + wave * 1024;
+        float* sb = sa + TILE_FLOATS;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[j] + koff), (lds_ptr_t)(sa + j * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b_src[j] + koff), (lds_ptr_t)(sb + j * 256), 16, 0, 0);
+        }
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -58,46 +72,41 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[4], rb[4];
-    if (k_begin < k_end) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const float4*>(a_ptr[i] + k_begin);
-            rb[i] = *reinterpret_cast<const float4*>(b_ptr[i] + k_begin);
-        }
-    }
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        __syncthreads();   // previous tile fully consumed
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4*>(&As[(ld_row + 32 * i) * LDS_LD + ld_c4]) = ra[i];
-            *reinterpret_cast<float4*>(&Bs[(ld_row + 32 * i) * LDS_LD + ld_c4]) = rb[i];
-        }
-        __syncthreads();
-        if (k0 + BK < k_end) {   // prefetch the next k-tile while this one is multiplied
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i] = *reinterpret_cast<const float4*>(a_ptr[i] + k0 + BK);
-                rb[i] = *reinterpret_cast<const float4*>(b_ptr[i] + k0 + BK);
-            }
-        }
+    // fragment read offsets (floats): row * 32 + ((2g + half) ^ fsw) * 4, fsw = (row>>1)&7 = (l31>>1)&7
+    const int fsw = (l31 >> 1) & 7;
+    const int a_row = (wm * 64 + l31) * BK, b_row = (wn * 64 + l31) * BK;
+
+    if (T > 0) issue(0, 0);
+    for (int t = 0; t < T; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t have landed
+        __syncthreads();                                    // everyone's have; everyone is done reading stage (t+1)&1
+        const float* As = smem + (t & 1) * (2 * TILE_FLOATS);
+        const float* Bs = As + TILE_FLOATS;
+        // all 16 fragment reads of this k-tile first, THEN the LDS-DMA of the next tile: hipcc waits vmcnt(0) before any
+        // ds_read that follows an outstanding LDS-DMA in program order, which would serialise the prefetch with the MFMAs
+        float4 af[BK / 8][2], bf[BK / 8][2];
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
-            const int koff = g * 8 + half * 4;
-            float4 af[2], bf[2];
+            const int koff = ((2 * g + half) ^ fsw) * 4;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                af[t] = *reinterpret_cast<const float4*>(&As[(wm * 64 + t * 32 + l31) * LDS_LD + koff]);
-                bf[t] = *reinterpret_cast<const float4*>(&Bs[(wn * 64 + t * 32 + l31) * LDS_LD + koff]);
+            for (int u = 0; u < 2; ++u) {
+                af[g][u] = *reinterpret_cast<const float4*>(As + a_row + u * 32 * BK + koff);
+                bf[g][u] = *reinterpret_cast<const float4*>(Bs + b_row + u * 32 * BK + koff);
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < T) issue((t + 1) & 1, (t + 1) * BK);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].x, bf[nt].x, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].y, bf[nt].y, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].z, bf[nt].z, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].w, bf[nt].w, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].x, bf[g][nt].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].y, bf[g][nt].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].z, bf[g][nt].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].w, bf[g][nt].w, acc[mt][nt], 0, 0, 0);
                 }
         }
     }
