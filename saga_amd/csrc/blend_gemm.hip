@@ -14,21 +14,43 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BM 128
 #define BN 128
-#define BK 32
-#define TILE_FLOATS (BM * BK)   // one operand tile: 128 rows x 32 floats = 16 KiB, 16 LDS-DMA pieces of 1 KiB
+// tuned on MI355X with scripts/ab/gemm_ab.hip (one process, interleaved rounds, random operands): 16-deep tiles with
+// three tiles in flight beside the one being multiplied (4 stages = 64 KB, two blocks per CU) run the forward shape at
+// 125 TFLOP/s and the split-K backward at 131 (5 stages: 134); 32-deep/2-stage gives 106/107.
+#define GEMM_BKT 16         // k-depth of an LDS tile
+#define GEMM_NST_FWD 4      // LDS stages, forward
+#define GEMM_NST_BWD 5      // LDS stages, backward (split-K)
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+template <int N>
+__device__ __forceinline__ void gemm_wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else static_assert(N == 0, "unsupported vmcnt");
+}
+
 // EPI 0: C[row][col] = acc + bias[col]           (C row stride ldc)
 // EPI 1: C[z][row][col] = acc                    (slab z = blockIdx.z, slab stride M*ldc)
-template <int EPI>
+// BKT  : k-depth of one LDS tile (16 or 32); NST: LDS stages (NST-1 tiles in flight beside the one being multiplied)
+template <int EPI, int BKT, int NST>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ Bt, int ldb, float* __restrict__ C,
                                                           int ldc, const float* __restrict__ bias, int M, int N, int K,
                                                           int kchunk, int tiles_m) {
+    constexpr int TILE_FLOATS = BM * BKT;            // one operand tile
+    constexpr int PPW = TILE_FLOATS * 4 / 1024 / 4;  // 1-KiB LDS-DMA pieces per wave per operand tile: 4 (BKT 32) / 2 (16)
+    constexpr int RPP = 1024 / (BKT * 4);            // tile rows per piece: 8 / 16
+    constexpr int CPR = BKT / 4;                     // 16-B chunks per row: 8 / 4
     // ONE shared array (a second LDS object beside an LDS-DMA target makes hipcc drain vmcnt before every ds_read)
-    __shared__ __attribute__((aligned(1024))) float smem[2 * 2 * TILE_FLOATS];   // [stage][A|B][128][32]
+    __shared__ __attribute__((aligned(1024))) float smem[NST * 2 * TILE_FLOATS];   // [stage][A|B][128][BKT]
 
     // consecutive blocks walk M first so the (large, batch-shared) Bt tile stays hot in L2 while A is re-read
     const int tile_m = blockIdx.x % tiles_m;
@@ -36,29 +58,33 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int k_begin = blockIdx.z * kchunk;
     const int k_end = min(K, k_begin + kchunk);
-    const int T = (k_end - k_begin) / BK;
+    const int T = (k_end - k_begin) / BKT;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
 
-    // LDS-DMA source addresses: piece p = wave*4 + j covers tile rows 8p .. 8p+7; lane -> (row 8p + lane>>3, slot lane&7)
-    // and fetches the 16-B k-chunk slot ^ ((row>>1)&7) of that row.
-    const float* a_src[4];
-    const float* b_src[4];
+    // bank-conflict swizzle of the 16-B slot within a row: BKT 32 (128-B rows, two per bank row): (row>>1)&7;
+    // BKT 16 (64-B rows, four per bank row): (row>>2)&3 -- the 16 lanes of every ds_read_b128 group hit 16 distinct slots
+    auto swz = [](int row) { return BKT == 32 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+
+    // LDS-DMA source addresses: piece p = wave*PPW + j covers tile rows RPP*p ..; lane -> (row, slot) and fetches the
+    // 16-B k-chunk slot ^ swz(row) of that row.
+    const float* a_src[PPW];
+    const float* b_src[PPW];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = (wave * 4 + j) * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    for (int j = 0; j < PPW; ++j) {
+        const int row = (wave * PPW + j) * RPP + lane / CPR;
+        const int chunk = (lane % CPR) ^ swz(row);
         a_src[j] = A + (size_t)min(m0 + row, M - 1) * lda + k_begin + chunk * 4;
         b_src[j] = Bt + (size_t)min(n0 + row, N - 1) * ldb + k_begin + chunk * 4;
     }
     auto issue = [&](int stage, int koff) {
-        float* sa = smem + stage * (2 * TILE_FLOATS) + wave * 1024;
+        float* sa = smem + stage * (2 * TILE_FLOATS) + wave * (PPW * 256);
         float* sb = sa + TILE_FLOATS;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PPW; ++j) {
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[j] + koff), (lds_ptr_t)(sa + j * 256), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b_src[j] + koff), (lds_ptr_t)(sb + j * 256), 16, 0, 0);
         }
@@ -72,33 +98,37 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fragment read offsets (floats): row * 32 + ((2g + half) ^ fsw) * 4, fsw = (row>>1)&7 = (l31>>1)&7
-    const int fsw = (l31 >> 1) & 7;
-    const int a_row = (wm * 64 + l31) * BK, b_row = (wn * 64 + l31) * BK;
+    // fragment read offsets (floats): row * BKT + ((2g + half) ^ swz(row)) * 4; swz(row) depends on l31 only
+    const int fsw = swz(l31);
+    const int a_row = (wm * 64 + l31) * BKT, b_row = (wn * 64 + l31) * BKT;
 
-    if (T > 0) issue(0, 0);
-    for (int t = 0; t < T; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t have landed
-        __syncthreads();                                    // everyone's have; everyone is done reading stage (t+1)&1
-        const float* As = smem + (t & 1) * (2 * TILE_FLOATS);
-        const float* Bs = As + TILE_FLOATS;
-        // all 16 fragment reads of this k-tile first, THEN the LDS-DMA of the next tile: hipcc waits vmcnt(0) before any
-        // ds_read that follows an outstanding LDS-DMA in program order, which would serialise the prefetch with the MFMAs
-        float4 af[BK / 8][2], bf[BK / 8][2];
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < T) issue(s, s * BKT);
+    for (int t = 0; t < T; ++t) {
+        // tile t has landed once at most the NST-2 younger tiles are outstanding (fewer near the tail: drain)
+        if (NST > 2 && t + NST - 2 < T) gemm_wait_vmcnt<(NST - 2) * 2 * PPW>();
+        else gemm_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();       // everyone's pieces have; everyone is done reading stage (t-1) % NST
+        const float* As = smem + (t % NST) * (2 * TILE_FLOATS);
+        const float* Bs = As + TILE_FLOATS;
+        // all fragment reads of this k-tile first, THEN the LDS-DMA of a later tile: hipcc waits vmcnt(0) before any
+        // ds_read that follows an outstanding LDS-DMA in program order, which would serialise the prefetch with the MFMAs
+        float4 af[BKT / 8][2], bf[BKT / 8][2];
+#pragma unroll
+        for (int g = 0; g < BKT / 8; ++g) {
             const int koff = ((2 * g + half) ^ fsw) * 4;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                af[g][u] = *reinterpret_cast<const float4*>(As + a_row + u * 32 * BK + koff);
-                bf[g][u] = *reinterpret_cast<const float4*>(Bs + b_row + u * 32 * BK + koff);
+                af[g][u] = *reinterpret_cast<const float4*>(As + a_row + u * 32 * BKT + koff);
+                bf[g][u] = *reinterpret_cast<const float4*>(Bs + b_row + u * 32 * BKT + koff);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < T) issue((t + 1) & 1, (t + 1) * BK);
+        if (t + NST - 1 < T) issue((t + NST - 1) % NST, (t + NST - 1) * BKT);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
+        for (int g = 0; g < BKT / 8; ++g) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -114,6 +144,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* Cz = C;
     if (EPI == 1) Cz += (size_t)blockIdx.z * M * ldc;
+    const bool full = (m0 + BM <= M);       // N is always a multiple of BN here (Npad / 512)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int col = n0 + wn * 64 + nt * 32 + l31;
@@ -121,10 +152,16 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
         const float bv = (EPI == 0) ? bias[col] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
+            float* cp = Cz + (size_t)(m0 + wm * 64 + mt * 32 + 4 * half) * ldc + col;
+            if (full) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < M) Cz[(size_t)row * ldc + col] = acc[mt][nt][r] + bv;
+                for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * ldc] = acc[mt][nt][r] + bv;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row < M) Cz[(size_t)row * ldc + col] = acc[mt][nt][r] + bv;
+                }
             }
         }
     }
@@ -134,7 +171,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
 int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed, int B, hipStream_t st) {
     const int tiles_m = (B + BM - 1) / BM, tiles_n = m->Npad / BN;
     dim3 grid(tiles_m * tiles_n, 1, 1);
-    gemm_nt_f32_kernel<0><<<grid, 256, 0, st>>>(feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template, B, m->Npad,
+    gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD><<<grid, 256, 0, st>>>(feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template, B, m->Npad,
                                                 FEAT_K, FEAT_K, tiles_m);
     SAGA_LAUNCH_CHECK();
     return 0;
@@ -143,9 +180,9 @@ int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed
 // slabs[z][B][512] = g_v_posed[:, kz] . Bk[:, kz]^T
 int saga_launch_blend_bwd(const saga_model* m, const float* g_vposed, float* slabs, int B, hipStream_t st) {
     const int tiles_m = (B + BM - 1) / BM, tiles_n = FEAT_K / BN;
-    const int kchunk = saga_roundup((m->Npad + SAGA_BWD_SPLITK - 1) / SAGA_BWD_SPLITK, BK);
+    const int kchunk = saga_roundup((m->Npad + SAGA_BWD_SPLITK - 1) / SAGA_BWD_SPLITK, 32);
     dim3 grid(tiles_m * tiles_n, 1, SAGA_BWD_SPLITK);
-    gemm_nt_f32_kernel<1><<<grid, 256, 0, st>>>(g_vposed, m->Npad, m->Bk, m->Npad, slabs, FEAT_K, nullptr, B, FEAT_K,
+    gemm_nt_f32_kernel<1, GEMM_BKT, GEMM_NST_BWD><<<grid, 256, 0, st>>>(g_vposed, m->Npad, m->Bk, m->Npad, slabs, FEAT_K, nullptr, B, FEAT_K,
                                                 m->Npad, kchunk, tiles_m);
     SAGA_LAUNCH_CHECK();
     return 0;

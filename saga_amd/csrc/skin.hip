@@ -13,47 +13,71 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SKIN_THREADS 256
 
 // ---- forward -------------------------------------------------------------------------------------------
-// grid (ceil(V/256), B). verts[b,v] = (sum_k w_k A[b, j_k]) . [v_posed[b,v]; 1] + transl[b]
+// grid (ceil(V / (256*SKIN_VPT)), B). verts[b,v] = (sum_k w_k A[b, j_k]) . [v_posed[b,v]; 1] + transl[b]
+// One block = one candidate x 1024 vertices: A[b] (2.6 KB) is staged in LDS once, every lane owns SKIN_VPT vertices
+// (tile i: vertex base + i*256 + tid, so the 12-B per-lane accesses of a wave are one contiguous 768-B run) and issues
+// all of its loads before the barrier.  KW4: the compressed weight table has exactly 4 entries per vertex and is read
+// as one int4 + one float4.
+#define SKIN_VPT 4
+template <bool KW4>
 __global__ __launch_bounds__(SKIN_THREADS) void skin_fwd_kernel(const float* __restrict__ A, const float* __restrict__ v_posed,
                                                                 const int32_t* __restrict__ w_idx,
                                                                 const float* __restrict__ w_val,
                                                                 const float* __restrict__ transl, float* __restrict__ verts,
                                                                 int V, int Npad, int KW) {
-    __shared__ float sA[NJ * 12];
-    __shared__ float sIn[SKIN_THREADS * 3];
+    __shared__ __attribute__((aligned(16))) float sA[NJ * 12];
     const int b = blockIdx.y;
-    const int v0 = blockIdx.x * SKIN_THREADS;
+    const int vbase = blockIdx.x * (SKIN_THREADS * SKIN_VPT);
     const int tid = threadIdx.x;
     for (int i = tid; i < NJ * 12; i += SKIN_THREADS) sA[i] = A[(size_t)b * (NJ * 12) + i];
-    // coalesced stage of this tile's v_posed (3 floats per vertex) through LDS
-    const int nflt = min(SKIN_THREADS, V - v0) * 3;
-    const float* src = v_posed + (size_t)b * Npad + (size_t)v0 * 3;
-    for (int i = tid; i < nflt; i += SKIN_THREADS) sIn[i] = src[i];
+    const float* src = v_posed + (size_t)b * Npad;
+    float px[SKIN_VPT], py[SKIN_VPT], pz[SKIN_VPT];
+    int4 ji[SKIN_VPT];
+    float4 wv[SKIN_VPT];
+#pragma unroll
+    for (int i = 0; i < SKIN_VPT; ++i) {
+        const int v = min(vbase + i * SKIN_THREADS + tid, V - 1);
+        px[i] = src[v * 3]; py[i] = src[v * 3 + 1]; pz[i] = src[v * 3 + 2];
+        if (KW4) {
+            ji[i] = reinterpret_cast<const int4*>(w_idx)[v];
+            wv[i] = reinterpret_cast<const float4*>(w_val)[v];
+        }
+    }
+    const float tx = transl ? transl[b * 3] : 0.f, ty = transl ? transl[b * 3 + 1] : 0.f, tz = transl ? transl[b * 3 + 2] : 0.f;
     __syncthreads();
-    const int v = v0 + tid;
-    float o[3] = {0, 0, 0};
-    if (v < V) {
-        const float px = sIn[tid * 3], py = sIn[tid * 3 + 1], pz = sIn[tid * 3 + 2];
+    float* dst = verts + (size_t)b * V * 3;
+#pragma unroll
+    for (int i = 0; i < SKIN_VPT; ++i) {
+        const int v = vbase + i * SKIN_THREADS + tid;
+        if (v >= V) continue;
         float T[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) T[k] = 0.f;
-        for (int k = 0; k < KW; ++k) {
-            const float w = w_val[(size_t)v * KW + k];
-            if (w == 0.f) continue;
-            const float* a = sA + w_idx[(size_t)v * KW + k] * 12;
+        if (KW4) {
+            const int jj[4] = {ji[i].x, ji[i].y, ji[i].z, ji[i].w};
+            const float ww[4] = {wv[i].x, wv[i].y, wv[i].z, wv[i].w};
 #pragma unroll
-            for (int q = 0; q < 12; ++q) T[q] = fmaf(w, a[q], T[q]);
+            for (int k = 0; k < 4; ++k) {
+                const float4* a = reinterpret_cast<const float4*>(sA + jj[k] * 12);
+                const float4 a0 = a[0], a1 = a[1], a2 = a[2];
+                const float w = ww[k];
+                T[0] = fmaf(w, a0.x, T[0]); T[1] = fmaf(w, a0.y, T[1]); T[2] = fmaf(w, a0.z, T[2]); T[3] = fmaf(w, a0.w, T[3]);
+                T[4] = fmaf(w, a1.x, T[4]); T[5] = fmaf(w, a1.y, T[5]); T[6] = fmaf(w, a1.z, T[6]); T[7] = fmaf(w, a1.w, T[7]);
+                T[8] = fmaf(w, a2.x, T[8]); T[9] = fmaf(w, a2.y, T[9]); T[10] = fmaf(w, a2.z, T[10]); T[11] = fmaf(w, a2.w, T[11]);
+            }
+        } else {
+            for (int k = 0; k < KW; ++k) {
+                const float w = w_val[(size_t)v * KW + k];
+                if (w == 0.f) continue;
+                const float* a = sA + w_idx[(size_t)v * KW + k] * 12;
+#pragma unroll
+                for (int q = 0; q < 12; ++q) T[q] = fmaf(w, a[q], T[q]);
+            }
         }
-        const float tx = transl ? transl[b * 3] : 0.f, ty = transl ? transl[b * 3 + 1] : 0.f, tz = transl ? transl[b * 3 + 2] : 0.f;
-        o[0] = (T[0] * px + T[1] * py + T[2] * pz + T[3]) + tx;
-        o[1] = (T[4] * px + T[5] * py + T[6] * pz + T[7]) + ty;
-        o[2] = (T[8] * px + T[9] * py + T[10] * pz + T[11]) + tz;
+        dst[v * 3] = (T[0] * px[i] + T[1] * py[i] + T[2] * pz[i] + T[3]) + tx;
+        dst[v * 3 + 1] = (T[4] * px[i] + T[5] * py[i] + T[6] * pz[i] + T[7]) + ty;
+        dst[v * 3 + 2] = (T[8] * px[i] + T[9] * py[i] + T[10] * pz[i] + T[11]) + tz;
     }
-    __syncthreads();
-    sIn[tid * 3] = o[0]; sIn[tid * 3 + 1] = o[1]; sIn[tid * 3 + 2] = o[2];
-    __syncthreads();
-    float* dst = verts + ((size_t)b * V + v0) * 3;
-    for (int i = tid; i < nflt; i += SKIN_THREADS) dst[i] = sIn[i];
 }
 
 // joints[b, 0:55] = posed joints (chain translation) ; [55:55+E] = picked vertices ; [55+E:] = landmarks ; + transl
@@ -140,47 +164,73 @@ __global__ void joints_bwd_kernel(const float* __restrict__ g_joints, const int3
 }
 
 // ---- backward of skinning, part 1: g_v_posed = T^T g  (elementwise, HBM-bound) -------------------------------
-// grid (ceil(Npad/3/256), B): also zero-fills the pad columns of g_v_posed (the split-K GEMM reads them).
+// Same decomposition as the forward; grid x covers Npad/3 (+1) vertices so the pad columns of g_v_posed (read by the
+// split-K GEMM) are zero-filled by the lanes past V.
+template <bool KW4>
 __global__ __launch_bounds__(SKIN_THREADS) void skin_bwd_vposed_kernel(const float* __restrict__ A, const float* __restrict__ g_verts,
                                                                        const int32_t* __restrict__ w_idx,
                                                                        const float* __restrict__ w_val,
                                                                        float* __restrict__ g_vposed, int V, int Npad, int KW) {
-    __shared__ float sA[NJ * 12];
-    __shared__ float sIo[SKIN_THREADS * 3];
+    __shared__ __attribute__((aligned(16))) float sA[NJ * 12];
     const int b = blockIdx.y;
-    const int v0 = blockIdx.x * SKIN_THREADS;
+    const int vbase = blockIdx.x * (SKIN_THREADS * SKIN_VPT);
     const int tid = threadIdx.x;
     for (int i = tid; i < NJ * 12; i += SKIN_THREADS) sA[i] = A[(size_t)b * (NJ * 12) + i];
-    const int nv = max(0, min(SKIN_THREADS, V - v0));
-    const float* src = g_verts + ((size_t)b * V + v0) * 3;
-    for (int i = tid; i < nv * 3; i += SKIN_THREADS) sIo[i] = src[i];
+    const float* src = g_verts + (size_t)b * V * 3;
+    float gx[SKIN_VPT], gy[SKIN_VPT], gz[SKIN_VPT];
+    int4 ji[SKIN_VPT];
+    float4 wv[SKIN_VPT];
+#pragma unroll
+    for (int i = 0; i < SKIN_VPT; ++i) {
+        const int v = min(vbase + i * SKIN_THREADS + tid, V - 1);
+        gx[i] = src[v * 3]; gy[i] = src[v * 3 + 1]; gz[i] = src[v * 3 + 2];
+        if (KW4) {
+            ji[i] = reinterpret_cast<const int4*>(w_idx)[v];
+            wv[i] = reinterpret_cast<const float4*>(w_val)[v];
+        }
+    }
     __syncthreads();
-    const int v = v0 + tid;
-    float o[3] = {0, 0, 0};
-    if (v < V) {
-        const float gx = sIo[tid * 3], gy = sIo[tid * 3 + 1], gz = sIo[tid * 3 + 2];
+    float* dst = g_vposed + (size_t)b * Npad;
+#pragma unroll
+    for (int i = 0; i < SKIN_VPT; ++i) {
+        const int v = vbase + i * SKIN_THREADS + tid;
+        if (v >= V) {
+            // pad columns [3V, Npad)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (v * 3 + c < Npad) dst[v * 3 + c] = 0.f;
+            continue;
+        }
         float T[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) T[k] = 0.f;
-        for (int k = 0; k < KW; ++k) {
-            const float w = w_val[(size_t)v * KW + k];
-            if (w == 0.f) continue;
-            const float* a = sA + w_idx[(size_t)v * KW + k] * 12;
+        if (KW4) {
+            const int jj[4] = {ji[i].x, ji[i].y, ji[i].z, ji[i].w};
+            const float ww[4] = {wv[i].x, wv[i].y, wv[i].z, wv[i].w};
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 4; ++k) {
+                const float4* a = reinterpret_cast<const float4*>(sA + jj[k] * 12);
+                const float4 a0 = a[0], a1 = a[1], a2 = a[2];
+                const float w = ww[k];
+                T[0] = fmaf(w, a0.x, T[0]); T[1] = fmaf(w, a0.y, T[1]); T[2] = fmaf(w, a0.z, T[2]);
+                T[3] = fmaf(w, a1.x, T[3]); T[4] = fmaf(w, a1.y, T[4]); T[5] = fmaf(w, a1.z, T[5]);
+                T[6] = fmaf(w, a2.x, T[6]); T[7] = fmaf(w, a2.y, T[7]); T[8] = fmaf(w, a2.z, T[8]);
+            }
+        } else {
+            for (int k = 0; k < KW; ++k) {
+                const float w = w_val[(size_t)v * KW + k];
+                if (w == 0.f) continue;
+                const float* a = sA + w_idx[(size_t)v * KW + k] * 12;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) T[r * 3 + c] = fmaf(w, a[r * 4 + c], T[r * 3 + c]);
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) T[r * 3 + c] = fmaf(w, a[r * 4 + c], T[r * 3 + c]);
+            }
         }
-        o[0] = T[0] * gx + T[3] * gy + T[6] * gz;
-        o[1] = T[1] * gx + T[4] * gy + T[7] * gz;
-        o[2] = T[2] * gx + T[5] * gy + T[8] * gz;
+        dst[v * 3] = T[0] * gx[i] + T[3] * gy[i] + T[6] * gz[i];
+        dst[v * 3 + 1] = T[1] * gx[i] + T[4] * gy[i] + T[7] * gz[i];
+        dst[v * 3 + 2] = T[2] * gx[i] + T[5] * gy[i] + T[8] * gz[i];
     }
-    __syncthreads();
-    sIo[tid * 3] = o[0]; sIo[tid * 3 + 1] = o[1]; sIo[tid * 3 + 2] = o[2];   // rows >= V hold zeros -> pad fill
-    __syncthreads();
-    const int n_out = max(0, min(SKIN_THREADS * 3, Npad - v0 * 3));
-    float* dst = g_vposed + (size_t)b * Npad + (size_t)v0 * 3;
-    for (int i = tid; i < n_out; i += SKIN_THREADS) dst[i] = sIo[i];
 }
 
 // ---- backward of skinning, part 2: dA[b, j, (r,c)] = sum_v Wd[v][j] * g[b,v,r] * [v_posed[b,v];1][c] ---------------
@@ -282,8 +332,12 @@ __global__ __launch_bounds__(256) void skin_bwd_dA_kernel(const float* __restric
 
 int saga_launch_skin_fwd(const saga_model* m, const float* A, const float* v_posed, const float* transl, float* verts, int B,
                          hipStream_t st) {
-    dim3 grid((m->V + SKIN_THREADS - 1) / SKIN_THREADS, B);
-    skin_fwd_kernel<<<grid, SKIN_THREADS, 0, st>>>(A, v_posed, m->w_idx, m->w_val, transl, verts, m->V, m->Npad, m->KW);
+    const int per_block = SKIN_THREADS * SKIN_VPT;
+    dim3 grid((m->V + per_block - 1) / per_block, B);
+    if (m->KW == 4)
+        skin_fwd_kernel<true><<<grid, SKIN_THREADS, 0, st>>>(A, v_posed, m->w_idx, m->w_val, transl, verts, m->V, m->Npad, m->KW);
+    else
+        skin_fwd_kernel<false><<<grid, SKIN_THREADS, 0, st>>>(A, v_posed, m->w_idx, m->w_val, transl, verts, m->V, m->Npad, m->KW);
     SAGA_LAUNCH_CHECK();
     return 0;
 }
@@ -307,8 +361,12 @@ int saga_launch_joints_bwd(const saga_model* m, const float* g_joints, float* g_
 
 int saga_launch_skin_bwd(const saga_model* m, const float* A, const float* g_verts, const float* v_posed, float* g_vposed,
                          float* dA, int dA_stride, int B, hipStream_t st) {
-    dim3 grid1((m->Npad / 3 + SKIN_THREADS) / SKIN_THREADS, B);
-    skin_bwd_vposed_kernel<<<grid1, SKIN_THREADS, 0, st>>>(A, g_verts, m->w_idx, m->w_val, g_vposed, m->V, m->Npad, m->KW);
+    const int per_block = SKIN_THREADS * SKIN_VPT;
+    dim3 grid1((m->Npad / 3 + 1 + per_block - 1) / per_block, B);     // covers every column of [0, Npad)
+    if (m->KW == 4)
+        skin_bwd_vposed_kernel<true><<<grid1, SKIN_THREADS, 0, st>>>(A, g_verts, m->w_idx, m->w_val, g_vposed, m->V, m->Npad, m->KW);
+    else
+        skin_bwd_vposed_kernel<false><<<grid1, SKIN_THREADS, 0, st>>>(A, g_verts, m->w_idx, m->w_val, g_vposed, m->V, m->Npad, m->KW);
     SAGA_LAUNCH_CHECK();
     skin_bwd_dA_kernel<<<(B + DA_CANDS - 1) / DA_CANDS, 256, 0, st>>>(g_verts, v_posed, m->Wd, dA, B, m->V, m->Npad, dA_stride);
     SAGA_LAUNCH_CHECK();
