@@ -5,9 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one fitting iteration of stage 3 (every loss term active) over B candidates on each GPU:
-optimizer.zero_grad, 6D->aa + VPoser decode, SMPL-X forward (full 10,475-vertex mesh), hand vertex normals,
-two bidirectional nearest-neighbour searches against 2,048 object points, signed distances + contact /
-collision losses, backward to the optimiser variables, Adam step.  Inputs are synthetic (random-init
+6D->aa + VPoser decode, SMPL-X forward (full 10,475-vertex mesh), hand vertex normals, two bidirectional
+nearest-neighbour searches against 2,048 object points, signed distances + contact / collision losses,
+backward to the optimiser variables, Adam step -- `saga_fit_step`, one kernel sequence with no host work in
+between (`--autograd` runs the same iteration as PyTorch autograd over the drop-in operators + torch.optim.Adam).  Inputs are synthetic (random-init
 shape-compatible body model, ellipsoid object clouds, seeded candidates) and resident in HBM before the timed
 region.  Candidates shard across ranks with no data-path collective ("weak" scaling: B per GPU is fixed);
 the end-of-fit all-gather for best-of-N runs once, after the timed region.
@@ -40,6 +41,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=4096, help='candidates per GPU')
     ap.add_argument('--obj-points', type=int, default=2048)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--autograd', action='store_true', help='PyTorch autograd + torch.optim.Adam instead of saga_fit_step')
     ap.add_argument('--cpu-batch', type=int, default=16)
     ap.add_argument('--cpu-iters', type=int, default=64)
     return ap.parse_args()
@@ -57,10 +59,13 @@ def build_problem(B, n_obj, rank, model_root, device):
     mk, mc, oc = make_grasp_targets(B, vo, seed=4815 + rank)
     cu = lambda a: torch.from_numpy(a).to(device)
     data = dict(markers=cu(mk), mc=cu(mc), oc=cu(oc), vo=cu(vo), no=cu(no))
+    data['problem'] = op.make_problem(data['markers'], data['vo'], data['no'], data['oc'], data['mc'])
     return op, vp, data
 
 
-def step(op, d, optimizer):
+def step(op, d, optimizer=None):
+    if optimizer is None:                      # native: whole iteration (incl. Adam) inside libsaga_hip.so
+        return op.native_step(2, d['problem'])[0]
     optimizer.zero_grad(set_to_none=True)
     loss, *_ = op.calc_loss_contact_map(d['markers'], d['vo'], d['no'], d['oc'], d['mc'], 'male', None, 2, 1.0)
     loss.sum().backward()
@@ -118,7 +123,7 @@ def main():
     tmp = tempfile.TemporaryDirectory()
     write_body_model(tmp.name, gender='male', seed=7)
     op, vp, d = build_problem(B, n_obj, rank, tmp.name, str(device))
-    optimizer = op.optimizer_s3
+    optimizer = op.optimizer_s3 if args.autograd else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -145,7 +150,7 @@ def main():
 
     # end-of-fit exchange (untimed): all-gather (loss, parameters) of every candidate, best-of-N per group of 8
     with torch.no_grad():
-        params = {k: v.detach() for k, v in op.body_params().items()}
+        params = {k: v.detach().reshape(B, -1) for k, v in op.body_params().items()}
     gl, gp = gather_candidates(loss.detach(), params, n_total=B * world)
     _, best_loss, _ = best_of_n(gl, gp, group_size=8)
 
@@ -169,6 +174,7 @@ def main():
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'GraspPose-Opt stage-3 iteration: SMPL-X fwd+bwd (V=10475, full mesh) + hand normals + '
                                    '2 bidirectional NN vs %d object points + contact/collision losses + Adam' % n_obj,
+                       'driver': 'torch autograd + torch.optim.Adam' if args.autograd else 'saga_fit_step (one kernel sequence)',
                        'candidates_per_gpu': B, 'candidates_total': B * world, 'object_points': n_obj,
                        'candidate_iterations_per_s': round(iters_per_s * B, 1),
                        'parallelism': 'candidates sharded, %d rank(s), no data-path collective' % world,

@@ -12,7 +12,7 @@
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it, nothing synchronises;
  *   - return 0 on success, a negative SAGA_E* code for argument errors, or a positive hipError_t;
  *     saga_last_error() returns a static, thread-local message for the last failure;
- *   - no entry point allocates device memory except saga_model_create (model constants).
+ *   - no entry point allocates device memory except saga_model_create / saga_decoder_create (constants).
  */
 #ifndef SAGA_HIP_H
 #define SAGA_HIP_H
@@ -195,6 +195,103 @@ int saga_grasp_loss_bwd(const saga_model_t* m, const saga_grasp_tables_t* tables
                         float* g_verts, int B, int O, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Whole fitting iteration on the device.  Replaces, for B independent candidates, one pass of the
+ * loop body `optimizer.zero_grad(); calc_loss_contact_map(...); loss.backward(); optimizer.step()`
+ * (WholeGraspPose/models/fittingop.py:377-384) with no host work between kernels:
+ *   optimiser variables -> SMPL-X arguments (:138-147: 6D -> axis-angle for the global orientation,
+ *   VPoser decode 32 -> 512 -> 512 -> 126 -> 21 x 6D -> axis-angle, hand PCA + pose mean),
+ *   saga_smplx_fwd, saga_grasp_loss_fwd, the weighted sum with its stage gates (:215-223),
+ *   saga_grasp_loss_bwd, saga_smplx_bwd, the reverse parameter maps, and torch.optim.Adam's update
+ *   (:77-84; default betas/eps, no weight decay) for the variable groups the stage's optimiser owns.
+ *
+ * The optimiser variables of a candidate (:71-76) are one packed row of SAGA_VAR_STRIDE floats:
+ * ------------------------------------------------------------------------------------------ */
+#define SAGA_VAR_STRIDE   112
+#define SAGA_VAR_VPOSE    0     /* vpose_rec [32]                      */
+#define SAGA_VAR_HAND     32    /* hand_pose [48] = left 24 | right 24 */
+#define SAGA_VAR_EYE      80    /* eye_pose  [6]  = leye 3 | reye 3    */
+#define SAGA_VAR_BETAS    86    /* betas     [10]                      */
+#define SAGA_VAR_TRANSL   96    /* transl_rec [3]                      */
+#define SAGA_VAR_ROT6D    99    /* glo_rot_rec [6]                     */
+#define SAGA_VAR_COUNT    105
+#define SAGA_GROUP_VPOSE  1     /* update_mask bits */
+#define SAGA_GROUP_HAND   2
+#define SAGA_GROUP_EYE    4
+#define SAGA_GROUP_BETAS  8
+#define SAGA_GROUP_TRANSL 16
+#define SAGA_GROUP_ROT6D  32
+#define SAGA_BODY_PARAM_COUNT 133  /* transl 3 | global_orient 3 | betas 10 | body_pose 63 | lh 24 | rh 24 | leye 3 | reye 3 */
+
+/* Parameter decoder constants: VPoser v1.0 decoder weights (human_body_prior `bodyprior_dec_fc1/fc2/out`,
+ * fittingop.py:65,142) and the SMPL-X hand PCA basis / means (inside `smplx`).  HOST pointers, copied. */
+typedef struct saga_decoder saga_decoder_t;
+typedef struct {
+    int32_t latent;           /* 32  (multiple of 16) */
+    int32_t hidden;           /* 512 (multiple of 128) */
+    int32_t n_body_joints;    /* 21  (decoder output = n_body_joints * 6 <= 128) */
+    int32_t n_pca;            /* 24  hand PCA components per hand */
+    const float* w1_host;     /* [hidden, latent]  torch Linear layout [out, in] */
+    const float* b1_host;     /* [hidden] */
+    const float* w2_host;     /* [hidden, hidden] */
+    const float* b2_host;     /* [hidden] */
+    const float* w3_host;     /* [n_body_joints*6, hidden] */
+    const float* b3_host;     /* [n_body_joints*6] */
+    const float* lhand_components_host;  /* [n_pca, 45] */
+    const float* rhand_components_host;  /* [n_pca, 45] */
+    const float* pose_mean_host;         /* [165] (zeros | hands_meanl | hands_meanr) */
+} saga_decoder_desc_t;
+int  saga_decoder_create(saga_decoder_t** out, const saga_decoder_desc_t* desc);
+void saga_decoder_destroy(saga_decoder_t* d);
+
+typedef struct {                 /* per-candidate fitting targets, DEVICE pointers (opt_grasppose.py:211-226) */
+    const float* obj;            /* [B,O,3] object points   */
+    const float* obj_normals;    /* [B,O,3]                 */
+    const float* markers_target; /* [B,M,3] sampled markers */
+    const float* c_markers;      /* [B,M]   marker contact map */
+    const float* c_object;       /* [B,O]   object contact map */
+    int32_t n_obj;               /* O */
+} saga_fit_problem_t;
+
+typedef struct {
+    int32_t stage;          /* 0,1,2: the loss gates of fittingop.py:215-223 */
+    int32_t only_rec;       /* fittingconfig['only_rec'] */
+    int32_t prior_contact;  /* fittingconfig['contact_loss'] == 'prior' */
+    int32_t update_mask;    /* SAGA_GROUP_* bits: the variables the optimiser of this stage owns (:77-79) */
+    int32_t adam_step;      /* 1-based step count of that optimiser */
+    float lr, beta1, beta2, eps;
+} saga_fit_step_cfg_t;
+
+/* floats of workspace saga_fit_step / saga_fit_decode need for B candidates and O object points */
+size_t saga_fit_workspace_floats(const saga_model_t* m, const saga_grasp_tables_t* tb, int B, int O);
+
+/* offset (in floats) of a named intermediate inside the workspace after saga_fit_step, or -1: "vertices" [B,V,3],
+ * "joints", "full_pose" [B,165], "shape", "terms" [B,16], "hand_rec", "hand_normals", "h2o_marker", "h2o_signed",
+ * "o2h_signed", "idx_m2o" / "idx_h2o" / "idx_o2h" (int32), "g_vertices", "g_full_pose", "g_shape", "g_transl",
+ * "grad" [B,SAGA_VAR_STRIDE] (gradient rows; the vpose columns are in "g_z" [B,128], regularisers excluded), "x6" */
+long long saga_fit_workspace_offset(const saga_model_t* m, const saga_grasp_tables_t* tb, int B, int O, const char* name);
+
+/*   vars   [B,SAGA_VAR_STRIDE]  in/out   optimiser variables
+ *   adam_m, adam_v [B,SAGA_VAR_STRIDE]  in/out  exp_avg / exp_avg_sq of the stage's optimiser
+ *   ws     workspace (contents undefined on entry; holds every intermediate of the iteration afterwards)
+ *   loss   [B]       out  per-candidate total loss (before the update)
+ *   loss_terms [B,16] out or NULL: total, rec, body_rec, marker contact, object contact, prior contact, hand collision,
+ *              object collision, foot, reg (loss_dict :225-236), then the four counts of :238-242, 2 pads
+ *   markers_rec [B,M,3] out  fitted markers (before the update) */
+int saga_fit_step(const saga_model_t* m, const saga_decoder_t* dec, const saga_grasp_tables_t* tb,
+                  const saga_fit_problem_t* prob, const saga_fit_step_cfg_t* cfg,
+                  float* vars, float* adam_m, float* adam_v, float* ws,
+                  float* loss, float* loss_terms, float* markers_rec, int B, void* stream);
+
+/* optimiser variables -> the SMPL-X parameter dict the reference saves (fittingop.py:466-475):
+ * body_params [B,SAGA_BODY_PARAM_COUNT] */
+int saga_fit_decode(const saga_decoder_t* dec, const float* vars, float* body_params, float* ws, int B, void* stream);
+
+/* best-of-iteration snapshot (fittingop.py:429-447) per candidate: where loss < best_loss, copy vars (taken after
+ * the update) and markers_rec (from before it) and lower best_loss. */
+int saga_fit_best_update(const float* loss, const float* vars, const float* markers_rec,
+                         float* best_loss, float* best_vars, float* best_markers, int B, int M, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel timing for bench.py (no counterpart in the reference, whose only timing hook is the
  * disabled `time per sample` log at WholeGraspPose/models/fittingop.py:376,491-492).
  * When enabled, every kernel launch of the entry points above is bracketed by a hipEvent pair on
@@ -212,7 +309,11 @@ int saga_grasp_loss_bwd(const saga_model_t* m, const saga_grasp_tables_t* tables
 #define SAGA_PROF_NORMALS    8
 #define SAGA_PROF_GRASP_FWD  9   /* fused normals + NN + signed distances + loss terms */
 #define SAGA_PROF_GRASP_BWD  10
-#define SAGA_PROF_NKERNELS   11
+#define SAGA_PROF_PARAMS_FWD 11  /* saga_fit_step: decoder MLP + 6D->aa + hand PCA */
+#define SAGA_PROF_LOSS_SUM   12  /* weighted sum + stage gates */
+#define SAGA_PROF_PARAMS_BWD 13  /* reverse parameter maps + decoder MLP backward */
+#define SAGA_PROF_ADAM       14
+#define SAGA_PROF_NKERNELS   15
 int saga_profile_enable(int on);
 int saga_profile_read(double* total_ms_host, int32_t* count_host);
 

@@ -44,6 +44,36 @@ class GraspTables(ctypes.Structure):
 
 GRASP_NTERMS = 16
 
+# packed optimiser-variable row (include/saga_hip.h SAGA_VAR_*)
+VAR_STRIDE = 112
+VAR_SLICES = {'vpose_rec': (0, 32), 'hand_pose': (32, 80), 'eye_pose': (80, 86), 'betas': (86, 96),
+              'transl_rec': (96, 99), 'glo_rot_rec': (99, 105)}
+VAR_GROUPS = {'vpose_rec': 1, 'hand_pose': 2, 'eye_pose': 4, 'betas': 8, 'transl_rec': 16, 'glo_rot_rec': 32}
+BODY_PARAM_COUNT = 133
+BODY_PARAM_SLICES = {'transl': (0, 3), 'global_orient': (3, 6), 'betas': (6, 16), 'body_pose': (16, 79),
+                     'left_hand_pose': (79, 103), 'right_hand_pose': (103, 127), 'leye_pose': (127, 130),
+                     'reye_pose': (130, 133)}
+
+
+class DecoderDesc(ctypes.Structure):
+    _fields_ = [('latent', ctypes.c_int32), ('hidden', ctypes.c_int32), ('n_body_joints', ctypes.c_int32),
+                ('n_pca', ctypes.c_int32),
+                ('w1_host', ctypes.c_void_p), ('b1_host', ctypes.c_void_p), ('w2_host', ctypes.c_void_p),
+                ('b2_host', ctypes.c_void_p), ('w3_host', ctypes.c_void_p), ('b3_host', ctypes.c_void_p),
+                ('lhand_components_host', ctypes.c_void_p), ('rhand_components_host', ctypes.c_void_p),
+                ('pose_mean_host', ctypes.c_void_p)]
+
+
+class FitProblem(ctypes.Structure):
+    _fields_ = [('obj', ctypes.c_void_p), ('obj_normals', ctypes.c_void_p), ('markers_target', ctypes.c_void_p),
+                ('c_markers', ctypes.c_void_p), ('c_object', ctypes.c_void_p), ('n_obj', ctypes.c_int32)]
+
+
+class FitStepCfg(ctypes.Structure):
+    _fields_ = [('stage', ctypes.c_int32), ('only_rec', ctypes.c_int32), ('prior_contact', ctypes.c_int32),
+                ('update_mask', ctypes.c_int32), ('adam_step', ctypes.c_int32),
+                ('lr', ctypes.c_float), ('beta1', ctypes.c_float), ('beta2', ctypes.c_float), ('eps', ctypes.c_float)]
+
 # name -> (restype, argtypes); every symbol include/saga_hip.h declares
 PROTOTYPES = {
     'saga_last_error': (ctypes.c_char_p, []),
@@ -70,12 +100,22 @@ PROTOTYPES = {
                             [ctypes.c_int, ctypes.c_int, c_stream]),
     'saga_grasp_loss_bwd': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(GraspTables)] + [ctypes.c_void_p] * 14 +
                             [ctypes.c_int, ctypes.c_int, c_stream]),
+    'saga_decoder_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(DecoderDesc)]),
+    'saga_decoder_destroy': (None, [ctypes.c_void_p]),
+    'saga_fit_workspace_floats': (ctypes.c_size_t, [ctypes.c_void_p, ctypes.POINTER(GraspTables), ctypes.c_int, ctypes.c_int]),
+    'saga_fit_workspace_offset': (ctypes.c_longlong, [ctypes.c_void_p, ctypes.POINTER(GraspTables), ctypes.c_int, ctypes.c_int,
+                                                      ctypes.c_char_p]),
+    'saga_fit_step': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(GraspTables), ctypes.POINTER(FitProblem),
+                                     ctypes.POINTER(FitStepCfg)] + [ctypes.c_void_p] * 7 + [ctypes.c_int, c_stream]),
+    'saga_fit_decode': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_stream]),
+    'saga_fit_best_update': (ctypes.c_int, [c_float_p] * 6 + [ctypes.c_int, ctypes.c_int, c_stream]),
     'saga_profile_enable': (ctypes.c_int, [ctypes.c_int]),
     'saga_profile_read': (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),
 }
 
 PROF_KERNELS = ['pose_fwd', 'blend_gemm_fwd', 'skin_fwd', 'joints', 'skin_bwd', 'blend_gemm_bwd', 'pose_bwd',
-                'chamfer_nn', 'vertex_normals', 'grasp_loss_fwd', 'grasp_loss_bwd']
+                'chamfer_nn', 'vertex_normals', 'grasp_loss_fwd', 'grasp_loss_bwd', 'params_fwd', 'loss_sum', 'params_bwd',
+                'adam']
 
 _lib = None
 

@@ -37,13 +37,16 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
     else static_assert(N == 0, "unsupported vmcnt");
 }
 
-// EPI 0: C[row][col] = acc + bias[col]           (C row stride ldc)
+// EPI 0: C[row][col] = acc + bias[col]           (C row stride ldc; bias may be NULL)
 // EPI 1: C[z][row][col] = acc                    (slab z = blockIdx.z, slab stride M*ldc)
+// EPI 2: C[row][col] = leaky_relu(acc + bias[col], 0.2)                    (VPoser decoder layers, fit_step.hip)
+// EPI 3: C[row][col] = acc * (aux[row][col] > 0 ? 1 : 0.2)                 (their backward; aux = the layer's output)
 // BKT  : k-depth of one LDS tile (16 or 32); NST: LDS stages (NST-1 tiles in flight beside the one being multiplied)
 template <int EPI, int BKT, int NST>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ Bt, int ldb, float* __restrict__ C,
-                                                          int ldc, const float* __restrict__ bias, int M, int N, int K,
+                                                          int ldc, const float* __restrict__ bias,
+                                                          const float* __restrict__ aux, int M, int N, int K,
                                                           int kchunk, int tiles_m) {
     constexpr int TILE_FLOATS = BM * BKT;            // one operand tile
     constexpr int PPW = TILE_FLOATS * 4 / 1024 / 4;  // 1-KiB LDS-DMA pieces per wave per operand tile: 4 (BKT 32) / 2 (16)
@@ -149,18 +152,26 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     for (int nt = 0; nt < 2; ++nt) {
         const int col = n0 + wn * 64 + nt * 32 + l31;
         if (col >= N) continue;
-        const float bv = (EPI == 0) ? bias[col] : 0.f;
+        const float bv = ((EPI == 0 || EPI == 2) && bias) ? bias[col] : 0.f;
+        auto epi = [&](float v, size_t off) -> float {
+            if (EPI == 2) return v > 0.f ? v : 0.2f * v;
+            if (EPI == 3) return aux[off] > 0.f ? v : 0.2f * v;
+            return v;
+        };
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            float* cp = Cz + (size_t)(m0 + wm * 64 + mt * 32 + 4 * half) * ldc + col;
+            const size_t cbase = (size_t)(m0 + wm * 64 + mt * 32 + 4 * half) * ldc + col;
             if (full) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * ldc] = acc[mt][nt][r] + bv;
+                for (int r = 0; r < 16; ++r) {
+                    const size_t off = cbase + (size_t)((r & 3) + 8 * (r >> 2)) * ldc;
+                    Cz[off] = epi(acc[mt][nt][r] + bv, off);
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (row < M) Cz[(size_t)row * ldc + col] = acc[mt][nt][r] + bv;
+                    if (row < M) Cz[(size_t)row * ldc + col] = epi(acc[mt][nt][r] + bv, (size_t)row * ldc + col);
                 }
             }
         }
@@ -171,7 +182,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
 int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed, int B, hipStream_t st) {
     const int tiles_m = (B + BM - 1) / BM, tiles_n = m->Npad / BN;
     dim3 grid(tiles_m * tiles_n, 1, 1);
-    gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD><<<grid, 256, 0, st>>>(feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template, B, m->Npad,
+    gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD><<<grid, 256, 0, st>>>(feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template, nullptr, B, m->Npad,
                                                 FEAT_K, FEAT_K, tiles_m);
     SAGA_LAUNCH_CHECK();
     return 0;
@@ -182,8 +193,27 @@ int saga_launch_blend_bwd(const saga_model* m, const float* g_vposed, float* sla
     const int tiles_m = (B + BM - 1) / BM, tiles_n = FEAT_K / BN;
     const int kchunk = saga_roundup((m->Npad + SAGA_BWD_SPLITK - 1) / SAGA_BWD_SPLITK, 32);
     dim3 grid(tiles_m * tiles_n, 1, SAGA_BWD_SPLITK);
-    gemm_nt_f32_kernel<1, GEMM_BKT, GEMM_NST_BWD><<<grid, 256, 0, st>>>(g_vposed, m->Npad, m->Bk, m->Npad, slabs, FEAT_K, nullptr, B, FEAT_K,
+    gemm_nt_f32_kernel<1, GEMM_BKT, GEMM_NST_BWD><<<grid, 256, 0, st>>>(g_vposed, m->Npad, m->Bk, m->Npad, slabs, FEAT_K, nullptr, nullptr, B, FEAT_K,
                                                 m->Npad, kchunk, tiles_m);
+    SAGA_LAUNCH_CHECK();
+    return 0;
+}
+
+// Small dense layers of the parameter decoder (fit_step.hip): C[M,N] = epi(A[M,K] . Bt[N,K]^T).  N a multiple of 128,
+// K a multiple of 16, rows of A and Bt 16-B aligned.
+int saga_launch_gemm_nt(int epi, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, const float* bias,
+                        const float* aux, int M, int N, int K, hipStream_t st) {
+    SAGA_CHECK_ARG(N % BN == 0 && K % GEMM_BKT == 0 && lda % 4 == 0 && ldb % 4 == 0 && M > 0, "gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
+    dim3 grid(tiles_m * tiles_n, 1, 1);
+    if (epi == 0)
+        gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD><<<grid, 256, 0, st>>>(A, lda, Bt, ldb, C, ldc, bias, aux, M, N, K, K, tiles_m);
+    else if (epi == 2)
+        gemm_nt_f32_kernel<2, GEMM_BKT, GEMM_NST_FWD><<<grid, 256, 0, st>>>(A, lda, Bt, ldb, C, ldc, bias, aux, M, N, K, K, tiles_m);
+    else if (epi == 3)
+        gemm_nt_f32_kernel<3, GEMM_BKT, GEMM_NST_FWD><<<grid, 256, 0, st>>>(A, lda, Bt, ldb, C, ldc, bias, aux, M, N, K, K, tiles_m);
+    else
+        SAGA_CHECK_ARG(false, "gemm_nt: unknown epilogue %d", epi);
     SAGA_LAUNCH_CHECK();
     return 0;
 }

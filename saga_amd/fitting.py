@@ -10,12 +10,14 @@ bidirectional nearest-neighbour searches) runs in ``libsaga_hip.so``; nothing is
 inside the loop (the reference crosses device->host->device for normals, ``fittingop.py:158-164``, and
 pulls 14 scalars per iteration, ``:225-242``).
 """
+import ctypes
 import os
 
 import numpy as np
 import torch
 import torch.optim as optim
 
+from . import _lib
 from . import smplx as _smplx
 from .geometry import point2point_signed, vertex_normals_subset
 from .grasp_loss import GraspTables, grasp_loss_terms
@@ -46,13 +48,16 @@ class FittingOP:
     ``./body_utils/body_models``), ``vposer`` (a module with ``decode(z, output_type='aa')``; default: a
     random-initialised :class:`VPoserDecoder`), ``indices`` (dict from :func:`load_grasp_indices`),
     ``smplx_kwargs`` (extra ``smplx.create`` kwargs, e.g. ``vertex_ids`` for reduced test meshes),
-    ``genders`` (which models to create; default both like the reference)."""
+    ``genders`` (which models to create; default both like the reference), ``native`` (default True: ``fitting``
+    drives ``saga_fit_step`` -- the whole iteration incl. Adam as one kernel sequence; False: PyTorch autograd over
+    the drop-in operators + ``torch.optim.Adam``, the form the reference has), ``record_history``."""
 
     def __init__(self, fittingconfig):
         cfg = dict(init_lr_h=0.008, num_iter=[300, 400, 500], batch_size=1, num_markers=143, device='cuda',
                    verbose=False, hand_ncomps=24, only_rec=False, contact_loss='contact', logger=print,
                    data_type='markers_143', body_model_path='./body_utils/body_models', vposer=None, indices=None,
-                   smplx_kwargs={}, genders=('male', 'female'), fused=True)
+                   smplx_kwargs={}, genders=('male', 'female'), fused=True, native=True,
+                   record_history=True)
         cfg.update(fittingconfig)
         for key, val in cfg.items():
             setattr(self, key, val)
@@ -79,15 +84,21 @@ class FittingOP:
             p.requires_grad_(False)
         self.fittingconfig = fittingconfig
 
-        # optimisation variables (fittingop.py:71-76) and the three Adam optimisers (:77-84)
-        z = lambda n: torch.zeros(B, n, device=self.device, requires_grad=True)
-        self.betas = z(10)
-        self.transl_rec = z(3)
-        self.glo_rot_rec = torch.tensor([[-1., 0, 0, 0, 0, 1]], device=self.device).repeat(B, 1).requires_grad_(True)
-        self.vpose_rec = z(32)
-        self.hand_pose = z(2 * self.hand_ncomps)
-        self.eye_pose = z(6)
+        # optimisation variables (fittingop.py:71-76): one packed row per candidate (the layout saga_fit_step works on);
+        # the named tensors are leaf views of it, so the autograd path and torch.optim see the same storage
+        self.vars = torch.zeros(B, _lib.VAR_STRIDE, device=self.device)
+        if 2 * self.hand_ncomps != 48:
+            self.native = False          # the packed row holds 2 x 24 hand PCA coefficients
+            self.hand_pose = torch.zeros(B, 2 * self.hand_ncomps, device=self.device, requires_grad=True)
+        for name, (a, b) in _lib.VAR_SLICES.items():
+            if name == 'hand_pose' and not self.native:
+                continue
+            setattr(self, name, self.vars[:, a:b].detach().requires_grad_(True))
+        with torch.no_grad():
+            self.glo_rot_rec.copy_(torch.tensor([[-1., 0, 0, 0, 0, 1]], device=self.device).expand(B, 6))
         self._make_optimizers()
+        self._decoder = None
+        self._ws = None
 
         idx = self.indices if self.indices is not None else load_grasp_indices()
         dev = self.device
@@ -105,6 +116,17 @@ class FittingOP:
         self.optimizer_s2 = optim.Adam([self.betas, self.transl_rec, self.glo_rot_rec, self.vpose_rec], lr=lr * 1.5)
         self.optimizer_s3 = optim.Adam([self.vpose_rec, self.hand_pose, self.eye_pose], lr=lr)
         self.optimizers = [self.optimizer_s1, self.optimizer_s2, self.optimizer_s3]
+        # state of the same three optimisers for the native step: exp_avg / exp_avg_sq rows + step counts
+        G = _lib.VAR_GROUPS
+        self._native_opt = [
+            dict(lr=lr * 2.0, mask=G['transl_rec'] | G['glo_rot_rec']),
+            dict(lr=lr * 1.5, mask=G['betas'] | G['transl_rec'] | G['glo_rot_rec'] | G['vpose_rec']),
+            dict(lr=lr, mask=G['vpose_rec'] | G['hand_pose'] | G['eye_pose']),
+        ]
+        for o in self._native_opt:
+            o['m'] = torch.zeros_like(self.vars)
+            o['v'] = torch.zeros_like(self.vars)
+            o['step'] = 0
 
     def variables(self):
         return {'betas': self.betas, 'transl_rec': self.transl_rec, 'glo_rot_rec': self.glo_rot_rec,
@@ -253,6 +275,127 @@ class FittingOP:
         }
         return loss, loss_dict, body_markers_rec, body_param, vertices_info, rhand_verts_rec, rh_normals, h2o_signed, o2h_signed
 
+    # ---- native iteration (saga_fit_step) --------------------------------------------------------------
+    def _native_handles(self):
+        """Decoder constants (VPoser weights + hand PCA of the current body model) and the workspace, created once."""
+        key = id(self.bm)
+        if self._decoder is None or self._decoder[0] != key:
+            vp, bm = self.vposer, self.bm
+            for attr in ('bodyprior_dec_fc1', 'bodyprior_dec_fc2', 'bodyprior_dec_out'):
+                if not hasattr(vp, attr):
+                    raise RuntimeError('native fitting needs a VPoser decoder with bodyprior_dec_fc1/fc2/out layers')
+            h = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)
+            arrs = [h(vp.bodyprior_dec_fc1.weight), h(vp.bodyprior_dec_fc1.bias), h(vp.bodyprior_dec_fc2.weight),
+                    h(vp.bodyprior_dec_fc2.bias), h(vp.bodyprior_dec_out.weight), h(vp.bodyprior_dec_out.bias),
+                    h(bm.left_hand_components), h(bm.right_hand_components), h(bm.pose_mean)]
+            p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+            desc = _lib.DecoderDesc(arrs[0].shape[1], arrs[0].shape[0], arrs[4].shape[0] // 6, arrs[6].shape[0], *[p(a) for a in arrs])
+            out = ctypes.c_void_p()
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.load().saga_decoder_create(ctypes.byref(out), ctypes.byref(desc)), 'saga_decoder_create')
+            if self._decoder is not None:
+                _lib.load().saga_decoder_destroy(self._decoder[1])
+            self._decoder = (key, out)
+        return self._decoder[1]
+
+    def _workspace(self, n_obj):
+        n = _lib.load().saga_fit_workspace_floats(self.bm.handle(self.device), ctypes.byref(self.tables.struct), self.batch_size, n_obj)
+        if self._ws is None or self._ws.numel() < n:
+            self._ws = torch.empty(n, device=self.device, dtype=torch.float32)
+        return self._ws
+
+    def make_problem(self, body_markers, verts_object, normal_object, contacts_object, contacts_markers):
+        """Device-resident fitting targets of a batch (kept alive by the returned object)."""
+        B = self.batch_size
+        c = lambda t, shape: t.detach().to(self.device, torch.float32).reshape(shape).contiguous()
+        O = verts_object.shape[1]
+        t = dict(obj=c(verts_object, (B, O, 3)), obj_normals=c(normal_object, (B, O, 3)),
+                 markers=c(body_markers, (B, self.tables.n_markers, 3)), c_markers=c(contacts_markers, (B, self.tables.n_markers)),
+                 c_object=c(contacts_object, (B, O)))
+        P = lambda x: ctypes.c_void_p(x.data_ptr())
+        t['struct'] = _lib.FitProblem(P(t['obj']), P(t['obj_normals']), P(t['markers']), P(t['c_markers']), P(t['c_object']), O)
+        t['loss'] = torch.empty(B, device=self.device)
+        t['markers_rec'] = torch.empty(B, self.tables.n_markers, 3, device=self.device)
+        return t
+
+    def native_step(self, ss, problem, loss_terms=None):
+        """One iteration of stage ``ss`` (loss, backward, Adam update of that stage's variables) in ``saga_fit_step``.
+        -> (loss [B], markers_rec [B,143,3]) of BEFORE the update, like the reference's loop body."""
+        if self.bm is None:
+            raise RuntimeError('select a body model first (self.bm = self.bm_male / bm_female)')
+        o = self._native_opt[ss]
+        o['step'] += 1
+        cfg = _lib.FitStepCfg(ss, int(bool(self.only_rec)), int(self.contact_loss == 'prior'), o['mask'], o['step'],
+                              o['lr'], 0.9, 0.999, 1e-8)
+        P = _lib.ptr
+        _lib.check(_lib.load().saga_fit_step(
+            self.bm.handle(self.device), self._native_handles(), ctypes.byref(self.tables.struct), ctypes.byref(problem['struct']),
+            ctypes.byref(cfg), P(self.vars), P(o['m']), P(o['v']), P(self._workspace(problem['struct'].n_obj)), P(problem['loss']),
+            P(loss_terms), P(problem['markers_rec']), self.batch_size, _lib.stream()), 'saga_fit_step')
+        return problem['loss'], problem['markers_rec']
+
+    def workspace_view(self, name, n_obj, shape, dtype=torch.float32):
+        """Intermediate of the last ``native_step`` by name (``saga_fit_workspace_offset``), e.g. ``'vertices'``."""
+        off = _lib.load().saga_fit_workspace_offset(self.bm.handle(self.device), ctypes.byref(self.tables.struct),
+                                                    self.batch_size, n_obj, name.encode())
+        if off < 0:
+            raise KeyError(name)
+        n = int(np.prod(shape))
+        t = self._ws[off:off + n]
+        return (t.view(dtype) if dtype != torch.float32 else t).view(*shape)
+
+    def decode_vars(self, packed=None):
+        """Packed variable rows -> the SMPL-X parameter dict the reference saves (fittingop.py:466-475)."""
+        packed = self.vars if packed is None else packed
+        B = packed.shape[0]
+        out = torch.empty(B, _lib.BODY_PARAM_COUNT, device=self.device)
+        n = _lib.load().saga_fit_workspace_floats(self.bm.handle(self.device), ctypes.byref(self.tables.struct), B, 1)
+        ws = self._ws if (self._ws is not None and self._ws.numel() >= n) else torch.empty(n, device=self.device)
+        _lib.check(_lib.load().saga_fit_decode(self._native_handles(), _lib.ptr(packed), _lib.ptr(out), _lib.ptr(ws), B,
+                                               _lib.stream()), 'saga_fit_decode')
+        return {k: out[:, a:b].clone() for k, (a, b) in _lib.BODY_PARAM_SLICES.items()}
+
+    def _fitting_native(self, body_markers, object_contact, markers_contact, verts_object, normal_object):
+        B, M = self.batch_size, self.tables.n_markers
+        prob = self.make_problem(body_markers, verts_object, normal_object, object_contact, markers_contact)
+        n_total = sum(self.num_iter)
+        hist = torch.zeros(n_total, B, 16, device=self.device) if self.record_history else None
+        best_loss = torch.full((B,), 10000.0, device=self.device)
+        best_vars = torch.zeros_like(self.vars)
+        best_markers = torch.zeros(B, M, 3, device=self.device)
+        any_best = False
+        smplxparams_list, markers_fit_list = [], []
+        lib = _lib.load()
+        P = _lib.ptr
+        it = 0
+        for ss in range(3):
+            for ii in range(self.num_iter[ss]):
+                loss, mk = self.native_step(ss, prob, None if hist is None else hist[it])
+                it += 1
+                if self.verbose and ii % 100 == 99:
+                    self.logger('[INFO][fitting][stage%d] iter=%d, mean loss %.5f' % (ss, ii, float(loss.mean())))
+                if not self.only_rec and ss == 2 and ii > 200:
+                    _lib.check(lib.saga_fit_best_update(P(loss), P(self.vars), P(mk), P(best_loss), P(best_vars), P(best_markers),
+                                                        B, M, _lib.stream()), 'saga_fit_best_update')
+                    any_best = True
+            has_iter = self.num_iter[ss] > 0
+            if ss == 2 and any_best:
+                never = best_loss >= 10000.0           # such a candidate keeps its final parameters (tmp_info is None, :464)
+                out = self.decode_vars(torch.where(never[:, None], self.vars, best_vars))
+                mfit = torch.where(never[:, None, None], prob['markers_rec'], best_markers)
+            else:
+                out, mfit = self.decode_vars(), (prob['markers_rec'].clone() if has_iter else None)
+            smplxparams_list.append(out)
+            markers_fit_list.append(None if mfit is None else mfit.cpu().numpy())
+        self.reset()
+        if hist is None:
+            save_loss = {k: np.zeros((0, B)) for k in LOSS_KEYS + COUNT_KEYS}
+        else:
+            h = hist.cpu().numpy()
+            save_loss = {k: h[:, :, i] for i, k in enumerate(LOSS_KEYS)}
+            save_loss.update({k: h[:, :, 10 + i].astype(np.int64) for i, k in enumerate(COUNT_KEYS)})
+        return markers_fit_list, smplxparams_list, save_loss
+
     def _snapshot(self):
         with torch.no_grad():
             return {k: v.detach().clone() for k, v in self.body_params().items()}
@@ -266,6 +409,8 @@ class FittingOP:
         if self.bm is None:
             raise ValueError('no body model was created for gender %r' % gender)
         self.faces = self.bm.faces
+        if self.native:
+            return self._fitting_native(body_markers, object_contact, markers_contact, verts_object, normal_object)
         B = self.batch_size
         smplxparams_list, markers_fit_list = [], []
         best_eval = torch.full((B,), 10000.0, device=self.device)
