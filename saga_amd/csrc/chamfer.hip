@@ -9,6 +9,7 @@
 
 #include "saga_common.h"
 #include "nn_scan.h"
+#include "nn_fast.h"
 
 void* saga_prof_begin(int id, void* stream);
 void saga_prof_end(void* scope);
@@ -53,8 +54,61 @@ __global__ __launch_bounds__(NTH) void nn_scan_kernel(const float* __restrict__ 
     }
 }
 
+// Database clouds that fit one LDS tile (every call SAGA makes: 2,048 object points / 778 hand vertices) take the
+// two-level scan of nn_fast.h: approximate expanded-form pass (3 fmas per pair) + exact re-evaluation of the candidate
+// chunks.  Same outputs as nn_scan_kernel, bit for bit.
+template <int NQ, int NTH>
+__global__ __launch_bounds__(NTH) void nn_fast_kernel(const float* __restrict__ q, const float* __restrict__ db,
+                                                      float* __restrict__ dist, int32_t* __restrict__ idx, int Pq, int Pd) {
+    __shared__ __attribute__((aligned(16))) float sdb[NNF_TILE_FLOATS(NN_TILE)];
+    __shared__ float sred[6 * (NTH / 64)];
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x * (NTH * NQ);
+    const float* qn = q + (size_t)n * Pq * 3;
+    const float* dn = db + (size_t)n * Pd * 3;
+    const NnfFrame f = nnf_frame(dn, Pd, sred, tid, NTH);
+    const int cnt_pad = nnf_stage_tile(sdb, dn, Pd, f, tid, NTH);
+    float ox[NQ], oy[NQ], oz[NQ], qx[NQ], qy[NQ], qz[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int p = min(q0 + tid + i * NTH, Pq - 1);
+        ox[i] = qn[p * 3]; oy[i] = qn[p * 3 + 1]; oz[i] = qn[p * 3 + 2];
+        qx[i] = ox[i] - f.cx; qy[i] = oy[i] - f.cy; qz[i] = oz[i] - f.cz;
+    }
+    __syncthreads();
+    float m1[NQ], m2[NQ], m3[NQ], best[NQ];
+    int c1[NQ], c2[NQ], bi[NQ];
+    nnf_scan<NQ>(sdb, cnt_pad / NNF_CH, qx, qy, qz, m1, m2, m3, c1, c2);
+    nnf_resolve<NQ>(sdb, cnt_pad / NNF_CH, f, 0, qx, qy, qz, ox, oy, oz, m1, m3, c1, c2, best, bi);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int p = q0 + tid + i * NTH;
+        if (p < Pq) {
+            if (dist) dist[(size_t)n * Pq + p] = best[i];
+            if (idx) idx[(size_t)n * Pq + p] = bi[i];
+        }
+    }
+}
+
 static int launch_scan(const float* q, const float* db, float* dist, int32_t* idx, int N, int Pq, int Pd, hipStream_t st) {
     if (!dist && !idx) return 0;
+    if (Pd <= NN_TILE) {
+        if (Pq <= 128) {
+            nn_fast_kernel<2, 64><<<dim3(1, N), 64, 0, st>>>(q, db, dist, idx, Pq, Pd);
+        } else if (Pq <= 256) {
+            nn_fast_kernel<2, 128><<<dim3(1, N), 128, 0, st>>>(q, db, dist, idx, Pq, Pd);
+        } else if (Pq <= 512) {
+            nn_fast_kernel<2, 256><<<dim3(1, N), 256, 0, st>>>(q, db, dist, idx, Pq, Pd);
+        } else if (Pq <= 1024) {
+            nn_fast_kernel<4, 256><<<dim3(1, N), 256, 0, st>>>(q, db, dist, idx, Pq, Pd);
+        } else {
+            dim3 grid((Pq + 256 * 8 - 1) / (256 * 8), N);
+            nn_fast_kernel<8, 256><<<grid, 256, 0, st>>>(q, db, dist, idx, Pq, Pd);
+        }
+        SAGA_LAUNCH_CHECK();
+        return 0;
+    }
     if (Pq <= 128) {
         nn_scan_kernel<2, 64><<<dim3(1, N), 64, 0, st>>>(q, db, dist, idx, Pq, Pd);
     } else if (Pq <= 256) {

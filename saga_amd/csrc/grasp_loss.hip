@@ -14,6 +14,7 @@
 
 #include "saga_common.h"
 #include "nn_scan.h"
+#include "nn_fast.h"
 
 void* saga_prof_begin(int id, void* stream);
 void saga_prof_end(void* scope);
@@ -210,6 +211,191 @@ __global__ __launch_bounds__(GL_THREADS) void grasp_loss_fwd_kernel(
     }
 }
 
+// ---- forward, object clouds that fit one LDS tile (O <= GL_TILE: every call SAGA makes) -------------------------------
+// Same outputs as grasp_loss_fwd_kernel, bit for bit, with the two-level scan of nn_fast.h: the object tile and the hand
+// tile live in LDS in their own centred frames as (-2x,-2y,-2z,|p|^2); the approximate pass costs 3 fmas per pair, the
+// exact pass re-evaluates the two candidate chunks of every query with the arithmetic of nn_scan.h.
+#define GLF_NO 4                // object points per lane and pass, object -> hand
+__global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
+    saga_grasp_tables_t tb, const float* __restrict__ verts, const int32_t* __restrict__ faces,
+    const int32_t* __restrict__ vf_ptr, const int32_t* __restrict__ vf_idx, const float* __restrict__ obj,
+    const float* __restrict__ obj_n, const float* __restrict__ mk_target, const float* __restrict__ c_mk,
+    const float* __restrict__ c_obj, float* __restrict__ terms, float* __restrict__ markers_rec,
+    float* __restrict__ hand_rec, float* __restrict__ hand_normals, float* __restrict__ h2o_marker,
+    float* __restrict__ h2o_signed, float* __restrict__ o2h_signed, int32_t* __restrict__ idx_m2o,
+    int32_t* __restrict__ idx_h2o, int32_t* __restrict__ idx_o2h, int V, int O) {
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) float sObj[NNF_TILE_FLOATS(GL_TILE)];        // framed object tile; later the hand normals
+    __shared__ __attribute__((aligned(16))) float sHand[NNF_TILE_FLOATS(GL_MAX_HAND)];   // framed hand tile
+    __shared__ float red[GL_THREADS / 64][GL_NSUM];
+    __shared__ float sbox[6 * (GL_THREADS / 64)];
+    float* sNrm = sObj;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int H = tb.n_hand, M = tb.n_markers, NQ = H + M;
+    const int Hpad = (H + NNF_CH - 1) / NNF_CH * NNF_CH;
+    const float* vb = verts + (size_t)b * V * 3;
+    const float* ob = obj + (size_t)b * O * 3;
+    const float* onb = obj_n + (size_t)b * O * 3;
+
+    // ---- x -> y queries: lane owns hand vertices / markers q = tid + i*GL_THREADS, i < GL_NQ ------------------
+    float qx[GL_NQ], qy[GL_NQ], qz[GL_NQ];
+    float hlo[3] = {INFINITY, INFINITY, INFINITY}, hhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int i = 0; i < GL_NQ; ++i) {
+        const int q = tid + i * GL_THREADS;
+        const int qc = min(q, NQ - 1);
+        const int v = qc < H ? tb.hand_ids[qc] : tb.marker_ids[qc - H];
+        qx[i] = vb[v * 3]; qy[i] = vb[v * 3 + 1]; qz[i] = vb[v * 3 + 2];
+        if (q < NQ) {
+            float* dst = q < H ? hand_rec + ((size_t)b * H + q) * 3 : markers_rec + ((size_t)b * M + (q - H)) * 3;
+            dst[0] = qx[i]; dst[1] = qy[i]; dst[2] = qz[i];
+            if (q < H) {
+                hlo[0] = fminf(hlo[0], qx[i]); hhi[0] = fmaxf(hhi[0], qx[i]);
+                hlo[1] = fminf(hlo[1], qy[i]); hhi[1] = fmaxf(hhi[1], qy[i]);
+                hlo[2] = fminf(hlo[2], qz[i]); hhi[2] = fmaxf(hhi[2], qz[i]);
+            }
+        }
+    }
+    // frames of the two clouds (block-wide bounding boxes) and the two tiles
+    const NnfFrame fo = nnf_frame(ob, O, sbox, tid, GL_THREADS);
+    const NnfFrame fh = nnf_frame_from_box(hlo, hhi, sbox, tid, GL_THREADS);
+    const int Opad = nnf_stage_tile(sObj, ob, O, fo, tid, GL_THREADS);
+#pragma unroll
+    for (int i = 0; i < GL_NQ; ++i) {
+        const int q = tid + i * GL_THREADS;
+        if (q < H) nnf_store_point(sHand, q, qx[i], qy[i], qz[i], fh);
+    }
+    for (int q = H + tid; q < Hpad; q += GL_THREADS) nnf_store_point(sHand, q, NN_FAR, NN_FAR, NN_FAR, fh);
+    __syncthreads();
+
+    float sums[GL_NSUM];
+#pragma unroll
+    for (int i = 0; i < GL_NSUM; ++i) sums[i] = 0.f;
+
+    // ---- x -> y : every hand vertex / marker finds its nearest object point -------------------------------
+    {
+        float cx[GL_NQ], cy[GL_NQ], cz[GL_NQ], m1[GL_NQ], m2[GL_NQ], m3[GL_NQ], best[GL_NQ];
+        int c1[GL_NQ], c2[GL_NQ], bi[GL_NQ];
+#pragma unroll
+        for (int i = 0; i < GL_NQ; ++i) { cx[i] = qx[i] - fo.cx; cy[i] = qy[i] - fo.cy; cz[i] = qz[i] - fo.cz; }
+        nnf_scan<GL_NQ>(sObj, Opad / NNF_CH, cx, cy, cz, m1, m2, m3, c1, c2);
+        nnf_resolve<GL_NQ>(sObj, Opad / NNF_CH, fo, 0, cx, cy, cz, qx, qy, qz, m1, m3, c1, c2, best, bi);
+#pragma unroll
+        for (int i = 0; i < GL_NQ; ++i) {
+            const int q = tid + i * GL_THREADS;
+            if (q >= NQ) continue;
+            const float x = qx[i], y = qy[i], z = qz[i];
+            const int k = bi[i];
+            const float dx = x - ob[k * 3], dy = y - ob[k * 3 + 1], dz = z - ob[k * 3 + 2];
+            const float dist = sqrtf((dx * dx + dy * dy) + dz * dz);
+            if (q < H) {
+                const float dot = (onb[k * 3] * dx + onb[k * 3 + 1] * dy) + onb[k * 3 + 2] * dz;
+                const float d = dist * sgn(dot);
+                h2o_signed[(size_t)b * H + q] = d;
+                idx_h2o[(size_t)b * H + q] = k;
+                const float vw = tb.hand_weights[q];
+                const bool near = (d < 0.02f) && (d > 0.f) && (powf(vw, 1.0f / 2.5f) > 0.7f);   // fittingop.py:195
+                sums[5] += fabsf(d) * (near ? vw : 0.f);                                          // :199,210
+                sums[6] += fabsf(d) * (d < 0.f ? 10.f : 0.f);                                     // :200,211
+                sums[8] += d < 0.f ? 1.f : 0.f;
+                sums[10] += (d < 0.001f && d > -0.001f) ? 1.f : 0.f;
+            } else {
+                const int p = q - H;
+                h2o_marker[(size_t)b * M + p] = dist;                                             // :183 quirk: unsigned
+                idx_m2o[(size_t)b * M + p] = k;
+                sums[3] += dist * c_mk[(size_t)b * M + p];                                        // :190
+                const float* tg = mk_target + ((size_t)b * M + p) * 3;
+                const float e = (fabsf(x - tg[0]) + fabsf(y - tg[1])) + fabsf(z - tg[2]);
+                sums[0] += e;                                                                     // :168
+                if (p < tb.n_body_markers) sums[1] += e;                                          // :169
+                sums[11] += dist < 0.f ? 1.f : 0.f;
+            }
+        }
+    }
+    // foot term: 0.1 * mean |z| (:173)
+    for (int i = tid; i < tb.n_foot; i += GL_THREADS) sums[2] += fabsf(vb[tb.foot_ids[i] * 3 + 2]);
+
+    // ---- hand normals (area-weighted, ascending face order) into the LDS space the object tile no longer needs ----
+    __syncthreads();
+    for (int i = tid; i < H; i += GL_THREADS) {
+        const int v = tb.hand_ids[i];
+        float nx = 0.f, ny = 0.f, nz = 0.f;
+        for (int e = vf_ptr[v]; e < vf_ptr[v + 1]; ++e) {
+            const int f = vf_idx[e];
+            const int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
+            const float ax = vb[i1 * 3] - vb[i0 * 3], ay = vb[i1 * 3 + 1] - vb[i0 * 3 + 1], az = vb[i1 * 3 + 2] - vb[i0 * 3 + 2];
+            const float bx = vb[i2 * 3] - vb[i0 * 3], by = vb[i2 * 3 + 1] - vb[i0 * 3 + 1], bz = vb[i2 * 3 + 2] - vb[i0 * 3 + 2];
+            nx += ay * bz - az * by;
+            ny += az * bx - ax * bz;
+            nz += ax * by - ay * bx;
+        }
+        const float sq = nx * nx + ny * ny + nz * nz;
+        if (sq > 0.f) { const float inv = 1.0f / sqrtf(sq); nx *= inv; ny *= inv; nz *= inv; }
+        if (isnan(nx)) { nx = 0.f; ny = 0.f; nz = 1.f; }
+        sNrm[i * 3] = nx; sNrm[i * 3 + 1] = ny; sNrm[i * 3 + 2] = nz;
+        float* dst = hand_normals + ((size_t)b * H + i) * 3;
+        dst[0] = nx; dst[1] = ny; dst[2] = nz;
+    }
+    __syncthreads();
+
+    // ---- y -> x : every object point finds its nearest HAND vertex (the marker direction is never used) ------
+    for (int k0 = 0; k0 < O; k0 += GL_THREADS * GLF_NO) {
+        float ox[GLF_NO], oy[GLF_NO], oz[GLF_NO], cx[GLF_NO], cy[GLF_NO], cz[GLF_NO], m1[GLF_NO], m2[GLF_NO], m3[GLF_NO], best[GLF_NO];
+        int c1[GLF_NO], c2[GLF_NO], bj[GLF_NO];
+#pragma unroll
+        for (int i = 0; i < GLF_NO; ++i) {
+            const int k = min(k0 + tid + i * GL_THREADS, O - 1);
+            ox[i] = ob[k * 3]; oy[i] = ob[k * 3 + 1]; oz[i] = ob[k * 3 + 2];
+            cx[i] = ox[i] - fh.cx; cy[i] = oy[i] - fh.cy; cz[i] = oz[i] - fh.cz;
+        }
+        nnf_scan<GLF_NO>(sHand, Hpad / NNF_CH, cx, cy, cz, m1, m2, m3, c1, c2);
+        nnf_resolve<GLF_NO>(sHand, Hpad / NNF_CH, fh, 0, cx, cy, cz, ox, oy, oz, m1, m3, c1, c2, best, bj);
+#pragma unroll
+        for (int i = 0; i < GLF_NO; ++i) {
+            const int k = k0 + tid + i * GL_THREADS;
+            if (k >= O) continue;
+            const int j = bj[i];
+            float hx, hy, hz;
+            nnf_tile_point(sHand, fh, j, hx, hy, hz);
+            const float dx = ox[i] - hx, dy = oy[i] - hy, dz = oz[i] - hz;
+            const float dist = sqrtf((dx * dx + dy * dy) + dz * dz);
+            const float dot = (sNrm[j * 3] * dx + sNrm[j * 3 + 1] * dy) + sNrm[j * 3 + 2] * dz;   // HAND normal (:68-71)
+            const float d = dist * sgn(dot);
+            o2h_signed[(size_t)b * O + k] = d;
+            idx_o2h[(size_t)b * O + k] = j;
+            sums[4] += fabsf(d) * c_obj[(size_t)b * O + k];                                  // :191
+            sums[7] += fabsf(d) * (d < 0.f ? 20.f : 0.f);                                    // :206,212
+            sums[9] += d < 0.f ? 1.f : 0.f;
+        }
+    }
+
+    // ---- per-candidate means: wave shuffles, then the four wave partials in wave order ---------------------
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int i = 0; i < GL_NSUM; ++i) {
+        float v = sums[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float sm[GL_NSUM];
+#pragma unroll
+        for (int i = 0; i < GL_NSUM; ++i) sm[i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+        float* t = terms + (size_t)b * NT;
+        t[0] = sm[0] / (float)(M * 3);
+        t[1] = sm[1] / (float)(tb.n_body_markers * 3);
+        t[2] = 0.1f * (sm[2] / (float)tb.n_foot);
+        t[3] = sm[3] / (float)M;
+        t[4] = sm[4] / (float)O;
+        t[5] = sm[5] / (float)H;
+        t[6] = sm[6] / (float)H;
+        t[7] = sm[7] / (float)O;
+        t[8] = sm[8]; t[9] = sm[9]; t[10] = sm[10]; t[11] = sm[11];
+        t[12] = 0.f; t[13] = 0.f; t[14] = 0.f; t[15] = 0.f;
+    }
+}
+
 // grad_vertices [B,V,3] (pre-zeroed) from the upstream gradients of the eight differentiable terms
 __global__ __launch_bounds__(GL_BWD_THREADS) void grasp_loss_bwd_kernel(
     saga_grasp_tables_t tb, const float* __restrict__ g_terms, const float* __restrict__ verts,
@@ -308,10 +494,16 @@ extern "C" int saga_grasp_loss_fwd(const saga_model_t* m, const saga_grasp_table
                        hand_normals && h2o_marker && h2o_signed && o2h_signed && idx_m2o && idx_h2o && idx_o2h,
                    "saga_grasp_loss_fwd: null buffer");
     void* prof = saga_prof_begin(SAGA_PROF_GRASP_FWD, stream);
-    grasp_loss_fwd_kernel<<<B, GL_THREADS, 0, (hipStream_t)stream>>>(*tb, verts, m->faces, m->vf_ptr, m->vf_idx, obj, obj_normals,
-                                                                     markers_target, c_markers, c_object, terms, markers_rec,
-                                                                     hand_rec, hand_normals, h2o_marker, h2o_signed, o2h_signed,
-                                                                     idx_m2o, idx_h2o, idx_o2h, m->V, O);
+    if (O <= GL_TILE)
+        grasp_loss_fwd_fast_kernel<<<B, GL_THREADS, 0, (hipStream_t)stream>>>(*tb, verts, m->faces, m->vf_ptr, m->vf_idx, obj,
+                                                                              obj_normals, markers_target, c_markers, c_object, terms,
+                                                                              markers_rec, hand_rec, hand_normals, h2o_marker,
+                                                                              h2o_signed, o2h_signed, idx_m2o, idx_h2o, idx_o2h, m->V, O);
+    else
+        grasp_loss_fwd_kernel<<<B, GL_THREADS, 0, (hipStream_t)stream>>>(*tb, verts, m->faces, m->vf_ptr, m->vf_idx, obj, obj_normals,
+                                                                         markers_target, c_markers, c_object, terms, markers_rec,
+                                                                         hand_rec, hand_normals, h2o_marker, h2o_signed, o2h_signed,
+                                                                         idx_m2o, idx_h2o, idx_o2h, m->V, O);
     saga_prof_end(prof);
     SAGA_LAUNCH_CHECK();
     return 0;

@@ -1,0 +1,241 @@
+// Two-level exact nearest-neighbour scan (gfx950): a cheap approximate pass picks the candidates, an exact pass decides.
+//
+// The exact squared distance of nn_scan.h costs 6 vector operations per (query, point) pair (3 subtractions, 1 multiply,
+// 2 fmas); the scan is FP32-VALU bound, so that count IS the run time.  Here the database tile is moved into a frame
+// centred on its own bounding box and stored as (-2x, -2y, -2z, |p|^2); then
+//        t(p) = fma(qz, -2z, fma(qy, -2y, fma(qx, -2x, |p|^2)))  =  |q - p|^2 - |q|^2  + rounding
+// costs 3 fmas per pair (two pairs per v_pk_fma_f32), and |q|^2 is the same for every p so argmin t = argmin distance
+// up to the rounding error, for which a rigorous bound E is carried (below).  Points are visited in chunks of 16; a
+// query keeps the three smallest chunk minima (m1 <= m2 <= m3) and the chunks (c1, c2) of the first two.
+//   * every point whose EXACT distance could be the minimum lies in a chunk with chunk-minimum <= m1 + margin;
+//   * if m3 > m1 + margin those chunks are c1 and c2 only: their 32 points are re-evaluated with the exact arithmetic
+//     of nn_scan.h (original coordinates, index order, strict '<') -- bit-identical to the sequential exact scan;
+//   * otherwise (three or more chunks inside the margin: ~1e-3 of the queries) the query takes a slow path that
+//     re-evaluates every chunk inside the margin exactly.
+// So the result is ALWAYS that of the exact scan (lowest index among the exact minima), never an approximation.
+//
+// Frame: per axis c = the bounding box's midpoint if the box satisfies hi <= 2 lo (same sign), else 0.  Then p/2 <= c <=
+// 2p for every point, so p - c is exact (Sterbenz) and p = fma(-0.5, -2(p - c), c) recovers the original coordinate
+// bit-for-bit from the LDS tile -- the exact pass needs no second copy of the cloud.
+//
+// Error bound, u = 2^-24, pc = p - c (exact), qc = fl(q - c), Rp >= |pc|, Rq = |qc|:
+//   |p|^2 chain: 3u Rp^2;  qc vs q - c: 2u Rq Rp;  three fma roundings: 3u (Rp^2 + 2 Rq Rp)   =>  |t - S| <= 8u Rp (Rp + Rq)
+// with S = |q - p|^2 - |q - c|^2 in real arithmetic; E = 10u Rp (Rp + Rq) leaves slack for evaluating E itself.
+// The oracle's fp32 distance d_o = D (1 + theta), |theta| <= 6u.  If p* is the exact-scan winner and p1 the approximate
+// one: t(p*) <= t(p1) + 2E + 13u D(p1), D(p1) <= t(p1) + E + |q - c|^2  =>  margin = 2E + 1e-6 (max(m1 + |qc|^2, 0) + E).
+#pragma once
+#include "nn_scan.h"
+
+#define NNF_CH 16
+#define NNF_CSTRIDE 68    // floats per chunk: 8 point pairs x {x0,x1,y0,y1,z0,z1,w0,w1} + 4 pad (per-lane chunk reads of the
+                          // exact pass then start on 16 different bank groups instead of one)
+#define NNF_TILE_FLOATS(n) (((n) + NNF_CH - 1) / NNF_CH * NNF_CSTRIDE)
+
+struct NnfFrame { float cx, cy, cz, rp; };
+
+__device__ __forceinline__ float nnf_axis_centre(float lo, float hi) {
+    if (lo > 0.f && hi <= 2.f * lo) return 0.5f * (lo + hi);
+    if (hi < 0.f && lo >= 2.f * hi) return 0.5f * (lo + hi);
+    return 0.f;
+}
+
+// Block-wide bounding box -> frame.  lo/hi: this thread's partial box (+INF/-INF when it holds no point).
+// sred: >= 6 * (nthreads/64) floats of LDS.  Contains barriers: every thread of the block calls it.
+__device__ __forceinline__ NnfFrame nnf_frame_from_box(float (&lo)[3], float (&hi)[3], float* sred, int tid, int nthreads) {
+    const int wave = tid >> 6, lane = tid & 63, nw = nthreads >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], o, 64));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o, 64));
+        }
+    }
+    __syncthreads();                     // sred may still be read by an earlier call
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { sred[wave * 6 + k] = lo[k]; sred[wave * 6 + 3 + k] = hi[k]; }
+    }
+    __syncthreads();
+    float c[3], r2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float l = sred[k], h = sred[3 + k];
+        for (int w = 1; w < nw; ++w) { l = fminf(l, sred[w * 6 + k]); h = fmaxf(h, sred[w * 6 + 3 + k]); }
+        c[k] = nnf_axis_centre(l, h);
+        const float r = fmaxf(h - c[k], c[k] - l);
+        r2 = fmaf(r, r, r2);
+    }
+    NnfFrame f;
+    f.cx = c[0]; f.cy = c[1]; f.cz = c[2];
+    f.rp = sqrtf(r2) * 1.0001f;
+    return f;
+}
+
+// bounding box of cnt points of a global cloud (thread tid of nthreads takes every nthreads-th point)
+__device__ __forceinline__ NnfFrame nnf_frame(const float* __restrict__ src, int cnt, float* sred, int tid, int nthreads) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = tid; k < cnt; k += nthreads) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = src[(size_t)k * 3 + a];
+            lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v);
+        }
+    }
+    return nnf_frame_from_box(lo, hi, sred, tid, nthreads);
+}
+
+__device__ __forceinline__ void nnf_store_point(float* __restrict__ s, int k, float x, float y, float z, const NnfFrame& f) {
+    const float px = x - f.cx, py = y - f.cy, pz = z - f.cz;       // exact for points inside the frame's box
+    const float w = __builtin_fmaf(pz, pz, __builtin_fmaf(py, py, px * px));
+    float* d = s + (k >> 4) * NNF_CSTRIDE + ((k & 15) >> 1) * 8 + (k & 1);
+    d[0] = -2.f * px; d[2] = -2.f * py; d[4] = -2.f * pz; d[6] = w;
+}
+
+// Stage cnt points (xyz rows) as a framed tile padded to a multiple of NNF_CH with far points.  Caller synchronises.
+__device__ __forceinline__ int nnf_stage_tile(float* __restrict__ s, const float* __restrict__ src, int cnt, const NnfFrame& f,
+                                              int tid, int nthreads) {
+    const int cnt_pad = (cnt + NNF_CH - 1) / NNF_CH * NNF_CH;
+    for (int k = tid; k < cnt_pad; k += nthreads) {
+        float x = NN_FAR, y = NN_FAR, z = NN_FAR;
+        if (k < cnt) { x = src[(size_t)k * 3]; y = src[(size_t)k * 3 + 1]; z = src[(size_t)k * 3 + 2]; }
+        nnf_store_point(s, k, x, y, z, f);
+    }
+    return cnt_pad;
+}
+
+// original coordinates of point j of a framed tile (bit-exact)
+__device__ __forceinline__ void nnf_tile_point(const float* __restrict__ s, const NnfFrame& f, int j, float& x, float& y, float& z) {
+    const float* p = s + (j >> 4) * NNF_CSTRIDE + ((j & 15) >> 1) * 8 + (j & 1);
+    x = __builtin_fmaf(-0.5f, p[0], f.cx); y = __builtin_fmaf(-0.5f, p[2], f.cy); z = __builtin_fmaf(-0.5f, p[4], f.cz);
+}
+
+// Approximate pass: NQ framed queries (qc = q - c) against n_chunks chunks.
+template <int NQ>
+__device__ __forceinline__ void nnf_scan(const float* __restrict__ s, int n_chunks, const float (&qx)[NQ], const float (&qy)[NQ],
+                                         const float (&qz)[NQ], float (&m1)[NQ], float (&m2)[NQ], float (&m3)[NQ], int (&c1)[NQ],
+                                         int (&c2)[NQ]) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) { m1[i] = INFINITY; m2[i] = INFINITY; m3[i] = INFINITY; c1[i] = -1; c2[i] = -1; }
+    // One step = two point pairs (4 points, 4 broadcast ds_read_b128) against the NQ queries: 2*NQ independent chains of
+    // three v_pk_fma_f32, issued stage by stage.  Steps are software-pipelined through two register sets (A, B): the
+    // reads of step g+1 are in flight while step g computes; a chunk is four steps (A,B,A,B), so the set that holds the
+    // next chunk's first step at the loop's back edge is A again and no register moves are needed.
+    auto load4 = [&](float4 (&r)[4], int c, int g) {
+        const float4* t = reinterpret_cast<const float4*>(s + c * NNF_CSTRIDE) + 4 * g;
+        r[0] = t[0]; r[1] = t[1]; r[2] = t[2]; r[3] = t[3];
+    };
+    float m[NQ];
+    auto step = [&](const float4 (&r)[4]) {
+        const nn_f2 X0 = {r[0].x, r[0].y}, Y0 = {r[0].z, r[0].w}, Z0 = {r[1].x, r[1].y}, W0 = {r[1].z, r[1].w};
+        const nn_f2 X1 = {r[2].x, r[2].y}, Y1 = {r[2].z, r[2].w}, Z1 = {r[3].x, r[3].y}, W1 = {r[3].z, r[3].w};
+        nn_f2 v0[NQ], v1[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const nn_f2 sx = {qx[i], qx[i]};
+            v0[i] = __builtin_elementwise_fma(sx, X0, W0);
+            v1[i] = __builtin_elementwise_fma(sx, X1, W1);
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const nn_f2 sy = {qy[i], qy[i]};
+            v0[i] = __builtin_elementwise_fma(sy, Y0, v0[i]);
+            v1[i] = __builtin_elementwise_fma(sy, Y1, v1[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const nn_f2 sz = {qz[i], qz[i]};
+            v0[i] = __builtin_elementwise_fma(sz, Z0, v0[i]);
+            v1[i] = __builtin_elementwise_fma(sz, Z1, v1[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            m[i] = __builtin_fminf(__builtin_fminf(m[i], v0[i].x), v0[i].y);
+            m[i] = __builtin_fminf(__builtin_fminf(m[i], v1[i].x), v1[i].y);
+        }
+    };
+    float4 A[4], B[4];
+    load4(A, 0, 0);
+    for (int c = 0; c < n_chunks; ++c) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) m[i] = INFINITY;
+        load4(B, c, 1);
+        step(A);
+        __builtin_amdgcn_sched_barrier(0);
+        load4(A, c, 2);
+        step(B);
+        __builtin_amdgcn_sched_barrier(0);
+        load4(B, c, 3);
+        step(A);
+        __builtin_amdgcn_sched_barrier(0);
+        load4(A, min(c + 1, n_chunks - 1), 0);
+        step(B);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            // sorted insert of m into (m1 <= m2 <= m3), chunks of the first two (selects, no branches)
+            const bool lt1 = m[i] < m1[i], lt2 = m[i] < m2[i];
+            m3[i] = __builtin_amdgcn_fmed3f(m[i], m2[i], m3[i]);
+            m2[i] = __builtin_amdgcn_fmed3f(m[i], m1[i], m2[i]);
+            m1[i] = __builtin_fminf(m[i], m1[i]);
+            int n2 = lt2 ? c : c2[i];
+            n2 = lt1 ? c1[i] : n2;
+            c2[i] = n2;
+            c1[i] = lt1 ? c : c1[i];
+        }
+    }
+}
+
+// exact evaluation of one chunk for one query (original coordinates o*), index order, strict '<'
+__device__ __forceinline__ void nnf_exact_chunk(const float* __restrict__ s, const NnfFrame& f, int ch, int base, float ox, float oy,
+                                                float oz, float& best, int& bi) {
+    const float4* t = reinterpret_cast<const float4*>(s + ch * NNF_CSTRIDE);
+#pragma unroll
+    for (int g = 0; g < NNF_CH / 2; ++g) {
+        const float4 a = t[2 * g], b = t[2 * g + 1];
+        const float x0 = __builtin_fmaf(-0.5f, a.x, f.cx), y0 = __builtin_fmaf(-0.5f, a.z, f.cy), z0 = __builtin_fmaf(-0.5f, b.x, f.cz);
+        const float x1 = __builtin_fmaf(-0.5f, a.y, f.cx), y1 = __builtin_fmaf(-0.5f, a.w, f.cy), z1 = __builtin_fmaf(-0.5f, b.y, f.cz);
+        const float d0 = nn_dist2(ox, oy, oz, x0, y0, z0);
+        const float d1 = nn_dist2(ox, oy, oz, x1, y1, z1);
+        const int k = base + ch * NNF_CH + 2 * g;
+        if (d0 < best) { best = d0; bi = k; }
+        if (d1 < best) { best = d1; bi = k + 1; }
+    }
+}
+
+// Exact pass.  qc*: framed queries (for the margin), o*: original query coordinates.  best/bi: exact squared distance
+// and index (global index of point 0 of the tile = base) of the sequential exact scan.
+template <int NQ>
+__device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_chunks, const NnfFrame& f, int base,
+                                            const float (&qx)[NQ], const float (&qy)[NQ], const float (&qz)[NQ],
+                                            const float (&ox)[NQ], const float (&oy)[NQ], const float (&oz)[NQ],
+                                            const float (&m1)[NQ], const float (&m3)[NQ], const int (&c1)[NQ], const int (&c2)[NQ],
+                                            float (&best)[NQ], int (&bi)[NQ]) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const float qq = __builtin_fmaf(qz[i], qz[i], __builtin_fmaf(qy[i], qy[i], qx[i] * qx[i])) * 1.001f;
+        const float E = 5.9604645e-7f * f.rp * (f.rp + sqrtf(qq));                       // 10 u Rp (Rp + Rq)
+        const float thr = m1[i] + (2.f * E + 1.0e-6f * (fmaxf(m1[i] + qq, 0.f) + E));
+        best[i] = INFINITY; bi[i] = 0;
+        if (m3[i] > thr) {
+            // the exact winner is in chunk c1 or c2: lower chunk first so that ties keep the lowest index
+            const int a = c2[i] < 0 ? c1[i] : min(c1[i], c2[i]);
+            const int b = c2[i] < 0 ? c1[i] : max(c1[i], c2[i]);
+            nnf_exact_chunk(s, f, a, base, ox[i], oy[i], oz[i], best[i], bi[i]);
+            nnf_exact_chunk(s, f, b, base, ox[i], oy[i], oz[i], best[i], bi[i]);
+        } else {
+            // slow path: every chunk whose approximate minimum is inside the margin, in index order
+            for (int c = 0; c < n_chunks; ++c) {
+                const float4* t = reinterpret_cast<const float4*>(s + c * NNF_CSTRIDE);
+                float m = INFINITY;
+#pragma unroll
+                for (int g = 0; g < NNF_CH / 2; ++g) {
+                    const float4 a = t[2 * g], b = t[2 * g + 1];
+                    const float v0 = __builtin_fmaf(qz[i], b.x, __builtin_fmaf(qy[i], a.z, __builtin_fmaf(qx[i], a.x, b.z)));
+                    const float v1 = __builtin_fmaf(qz[i], b.y, __builtin_fmaf(qy[i], a.w, __builtin_fmaf(qx[i], a.y, b.w)));
+                    m = __builtin_fminf(__builtin_fminf(m, v0), v1);
+                }
+                if (m <= thr) nnf_exact_chunk(s, f, c, base, ox[i], oy[i], oz[i], best[i], bi[i]);
+            }
+        }
+    }
+}

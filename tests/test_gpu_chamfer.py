@@ -40,6 +40,51 @@ def test_chamfer_ties_lowest_index():
     _check(lat + 0.5, lat)
 
 
+def _sphere(n, g):
+    v = torch.randn(n, 3, generator=g)
+    return v / v.norm(dim=1, keepdim=True)
+
+
+@pytest.mark.parametrize('case', ['offset_far', 'straddle_zero', 'negative_box', 'equidistant', 'grasp_like', 'huge_coords',
+                                  'coincident'])
+def test_chamfer_two_level_scan_adversarial(case):
+    """Single-tile databases take the approximate-then-exact scan (nn_fast.h); the result must stay that of the
+    sequential exact scan wherever the approximation is weakest: large offsets (cancellation), boxes that straddle
+    zero (no centring), every point equidistant (every chunk inside the margin -> slow path), coincident points."""
+    g = torch.Generator().manual_seed(sum(map(ord, case)))
+    N = 3
+    if case == 'offset_far':
+        c = torch.tensor([53.0, -31.0, 2.5])
+        y = torch.randn(N, 2048, 3, generator=g) * 0.03 + c
+        x = torch.cat([torch.randn(N, 500, 3, generator=g) * 0.05 + c, torch.randn(N, 300, 3, generator=g) * 2.0 + c], 1)
+    elif case == 'straddle_zero':
+        y = torch.randn(N, 2000, 3, generator=g) * 0.05
+        x = torch.randn(N, 900, 3, generator=g) * 0.07
+    elif case == 'negative_box':
+        c = torch.tensor([-0.8, -1.3, -0.4])
+        y = (torch.rand(N, 1999, 3, generator=g) - 0.5) * 0.1 + c
+        x = (torch.rand(N, 921, 3, generator=g) - 0.5) * 0.3 + c
+    elif case == 'equidistant':
+        c = torch.tensor([0.7, 0.2, 1.1])
+        y = torch.stack([_sphere(2048, g) for _ in range(N)]) * 0.05 + c
+        x = torch.randn(N, 256, 3, generator=g) * 1e-4 + c          # near the centre: all 2048 points nearly tie
+    elif case == 'grasp_like':
+        N = 24
+        c = torch.tensor([0.3, -0.4, 1.0])
+        y = torch.stack([_sphere(2048, g) for _ in range(N)]) * torch.tensor([0.06, 0.04, 0.03]) + c
+        near = torch.stack([_sphere(778, g) for _ in range(N)]) * torch.tensor([0.065, 0.045, 0.034]) + c
+        body = torch.randn(N, 143, 3, generator=g) * torch.tensor([0.3, 0.2, 0.8]) + torch.tensor([0.0, 0.0, 0.9])
+        x = torch.cat([near, body], 1)
+    elif case == 'huge_coords':
+        y = torch.randn(N, 1024, 3, generator=g) * 10.0 + 1000.0
+        x = torch.randn(N, 300, 3, generator=g) * 10.0 + 1000.0
+    else:
+        y = torch.randn(N, 640, 3, generator=g) * 0.1 + 0.5
+        x = y[:, ::3].clone()                                        # queries ON database points (distance 0)
+        y[:, 100:140] = y[:, 5:6]                                    # and a block of duplicates
+    _check(x.float().contiguous(), y.float().contiguous())
+
+
 def test_chamfer_both_call_forms_and_errors():
     import saga_amd.chamfer_distance as chd
     x = torch.randn(1, 5, 3).cuda()
