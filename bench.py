@@ -30,7 +30,45 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_TFLOPS = 157.3     # MI355X dense FP32 (vector = matrix), /opt/skills/guides/MI355X_MICROARCH.md
-V, K_FEAT = 10475, 512
+PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (same guide; ~6.3 TB/s achievable)
+V, K_ALG = 10475, 506       # algorithmic K of the blend contraction: 20 shape + 486 pose-feature columns (padded to 512)
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'round1_pmc_summary.json')
+
+
+def stage_rooflines(prof, steps, B, n_obj):
+    """Per-kernel achieved rate against the roofline that bounds it (SURVEY.md 8d figures x B / live HIP-event time)."""
+    ms = lambda k: prof[k][0] / max(prof[k][1], 1) if k in prof and prof[k][1] else None
+    out = {}
+
+    def add(name, key, bound, work, unit, peak):
+        t = ms(key)
+        if t:
+            rate = work / (t * 1e-3) / (1e12 if unit == 'TFLOP/s' else 1e9)
+            out[name] = {'bound': bound, 'ms': round(t, 4), 'achieved': round(rate, 2), 'unit': unit, 'peak': peak,
+                         'frac': round(rate / peak, 4)}
+    gemm = 2.0 * B * 3 * V * K_ALG
+    add('blend_gemm_fwd', 'blend_gemm_fwd', 'mfma', gemm, 'TFLOP/s', PEAK_F32_TFLOPS)
+    add('blend_gemm_bwd', 'blend_gemm_bwd', 'mfma', gemm, 'TFLOP/s', PEAK_F32_TFLOPS)
+    vb = 3 * V * 4.0                                           # bytes of one [V,3] row
+    add('skin_fwd', 'skin_fwd', 'hbm', B * 2 * vb, 'GB/s', PEAK_HBM_GBS)                 # read v_posed, write vertices
+    add('skin_bwd', 'skin_bwd', 'hbm', B * 3 * vb, 'GB/s', PEAK_HBM_GBS)                 # read g_vertices + v_posed, write g_v_posed
+    add('skin_bwd_dA_mfma', 'skin_bwd', 'mfma', B * 2.0 * V * 12 * 55, 'TFLOP/s', PEAK_F32_TFLOPS)
+    add('grasp_loss_bwd', 'grasp_loss_bwd', 'hbm', B * vb, 'GB/s', PEAK_HBM_GBS)         # dense g_vertices written once
+    add('pose_chain_fwd', 'pose_fwd', 'hbm', B * (512 + 55 * 36 + 165) * 4.0, 'GB/s', PEAK_HBM_GBS)
+    # NN: (143 + 778) x O point pairs per candidate, 8 FLOP each (3 sub, 1 mul, 2 fma), one pass serving both directions
+    add('grasp_loss_fwd_nn', 'grasp_loss_fwd', 'valu', B * (143 + 778) * n_obj * 8.0, 'TFLOP/s', PEAK_F32_TFLOPS)
+    return out
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (separate passes,
+    FETCH_SIZE doubled as the guide prescribes for gfx950); None when the summary is absent."""
+    try:
+        d = json.load(open(PMC_SUMMARY))
+        g = [v for k, v in d.items() if k.startswith('gemm_nt_f32_kernel') and v.get('hbm_bytes') and v.get('mean_us', 0) > 500]
+        return round(sum(x['hbm_bytes'] for x in g) / len(g)) if g else None
+    except (OSError, ValueError):
+        return None
 
 
 def parse():
@@ -160,7 +198,7 @@ def main():
         # dominant kernel: the FP32-MFMA blend contraction (forward + backward launches are the same kernel template)
         gemm_ms = prof['blend_gemm_fwd'][0] + prof['blend_gemm_bwd'][0]
         gemm_n = prof['blend_gemm_fwd'][1] + prof['blend_gemm_bwd'][1]
-        flop_per_launch = 2.0 * B * (3 * V) * K_FEAT           # algorithmic: [B,512] x [512,31425], fwd == bwd
+        flop_per_launch = 2.0 * B * (3 * V) * K_ALG            # algorithmic: [B,506] x [506,31425], fwd == bwd
         achieved = flop_per_launch / (gemm_ms / max(gemm_n, 1) * 1e-3) / 1e12 if gemm_n else None
         kernels = {k: {'ms_per_step': round(ms / args.steps, 4), 'launches_per_step': n / args.steps}
                    for k, (ms, n) in prof.items() if n}
@@ -178,11 +216,14 @@ def main():
                        'candidates_per_gpu': B, 'candidates_total': B * world, 'object_points': n_obj,
                        'candidate_iterations_per_s': round(iters_per_s * B, 1),
                        'parallelism': 'candidates sharded, %d rank(s), no data-path collective' % world,
-                       'best_of_8_mean_loss': float(best_loss.mean()), 'kernels': kernels},
+                       'best_of_8_mean_loss': float(best_loss.mean()), 'kernels': kernels,
+                       'stages': stage_rooflines(prof, args.steps, B, n_obj)},
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_f32_kernel (blend contraction, fwd+bwd launches)',
                          'achieved': None if achieved is None else round(achieved, 2), 'peak': PEAK_F32_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': None if achieved is None else round(achieved / PEAK_F32_TFLOPS, 4),
-                         'traffic': None},
+                         'traffic': pmc_traffic(),
+                         'traffic_note': 'HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/); '
+                                         'algorithmic bytes per launch = %d' % int(B * 3 * V * 4 + B * 512 * 4 + 3 * V * 512 * 4)},
         }
         if not args.no_cpu_baseline:
             cand_per_s, threads, dt = cpu_baseline(tmp.name, vp, n_obj, args.cpu_batch, args.cpu_iters)

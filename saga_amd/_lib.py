@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libsaga_hip.so')
+LIB_PATH = os.environ.get('SAGA_HIP_LIB') or os.path.join(_HERE, 'lib', 'libsaga_hip.so')   # override: A/B builds
 
 c_float_p = ctypes.c_void_p
 c_int_p = ctypes.c_void_p

@@ -15,6 +15,7 @@
 #include "saga_common.h"
 #include "nn_scan.h"
 #include "nn_fast.h"
+#include "vertex_normal.h"
 
 void* saga_prof_begin(int id, void* stream);
 void saga_prof_end(void* scope);
@@ -33,8 +34,8 @@ void saga_prof_end(void* scope);
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 
 __global__ __launch_bounds__(GL_THREADS) void grasp_loss_fwd_kernel(
-    saga_grasp_tables_t tb, const float* __restrict__ verts, const int32_t* __restrict__ faces,
-    const int32_t* __restrict__ vf_ptr, const int32_t* __restrict__ vf_idx, const float* __restrict__ obj,
+    saga_grasp_tables_t tb, const float* __restrict__ verts, const int32_t* __restrict__ vf_ptr,
+    const int32_t* __restrict__ vf_tri, const float* __restrict__ obj,
     const float* __restrict__ obj_n, const float* __restrict__ mk_target, const float* __restrict__ c_mk,
     const float* __restrict__ c_obj, float* __restrict__ terms, float* __restrict__ markers_rec,
     float* __restrict__ hand_rec, float* __restrict__ hand_normals, float* __restrict__ h2o_marker,
@@ -75,20 +76,8 @@ __global__ __launch_bounds__(GL_THREADS) void grasp_loss_fwd_kernel(
     }
     // ---- hand normals (area-weighted, ascending face order) --------------------------------------------------
     for (int i = tid; i < H; i += GL_THREADS) {
-        const int v = tb.hand_ids[i];
-        float nx = 0.f, ny = 0.f, nz = 0.f;
-        for (int e = vf_ptr[v]; e < vf_ptr[v + 1]; ++e) {
-            const int f = vf_idx[e];
-            const int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
-            const float ax = vb[i1 * 3] - vb[i0 * 3], ay = vb[i1 * 3 + 1] - vb[i0 * 3 + 1], az = vb[i1 * 3 + 2] - vb[i0 * 3 + 2];
-            const float bx = vb[i2 * 3] - vb[i0 * 3], by = vb[i2 * 3 + 1] - vb[i0 * 3 + 1], bz = vb[i2 * 3 + 2] - vb[i0 * 3 + 2];
-            nx += ay * bz - az * by;
-            ny += az * bx - ax * bz;
-            nz += ax * by - ay * bx;
-        }
-        const float sq = nx * nx + ny * ny + nz * nz;
-        if (sq > 0.f) { const float inv = 1.0f / sqrtf(sq); nx *= inv; ny *= inv; nz *= inv; }
-        if (isnan(nx)) { nx = 0.f; ny = 0.f; nz = 1.f; }
+        float nx, ny, nz;
+        saga_vertex_normal(vb, vf_ptr, vf_tri, tb.hand_ids[i], nx, ny, nz);
         sNrm[i * 3] = nx; sNrm[i * 3 + 1] = ny; sNrm[i * 3 + 2] = nz;
         float* dst = hand_normals + ((size_t)b * H + i) * 3;
         dst[0] = nx; dst[1] = ny; dst[2] = nz;
@@ -211,14 +200,29 @@ __global__ __launch_bounds__(GL_THREADS) void grasp_loss_fwd_kernel(
     }
 }
 
+#ifdef GL_PHASE_TIMING
+__device__ unsigned long long gl_phase[8];
+extern "C" int saga_debug_read_phases(unsigned long long* out) {
+    unsigned long long z[8] = {0};
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(gl_phase), sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(gl_phase), z, sizeof(z));
+    return (int)e;
+}
+#define GL_T(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long t_ = clock64(); atomicAdd(&gl_phase[i], t_ - t_prev); t_prev = t_; } } while (0)
+#define GL_T0() unsigned long long t_prev = clock64()
+#else
+#define GL_T(i)
+#define GL_T0()
+#endif
+
 // ---- forward, object clouds that fit one LDS tile (O <= GL_TILE: every call SAGA makes) -------------------------------
 // Same outputs as grasp_loss_fwd_kernel, bit for bit, with the two-level scan of nn_fast.h: the object tile and the hand
 // tile live in LDS in their own centred frames as (-2x,-2y,-2z,|p|^2); the approximate pass costs 3 fmas per pair, the
 // exact pass re-evaluates the two candidate chunks of every query with the arithmetic of nn_scan.h.
 #define GLF_NO 4                // object points per lane and pass, object -> hand
 __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
-    saga_grasp_tables_t tb, const float* __restrict__ verts, const int32_t* __restrict__ faces,
-    const int32_t* __restrict__ vf_ptr, const int32_t* __restrict__ vf_idx, const float* __restrict__ obj,
+    saga_grasp_tables_t tb, const float* __restrict__ verts, const int32_t* __restrict__ vf_ptr,
+    const int32_t* __restrict__ vf_tri, const float* __restrict__ obj,
     const float* __restrict__ obj_n, const float* __restrict__ mk_target, const float* __restrict__ c_mk,
     const float* __restrict__ c_obj, float* __restrict__ terms, float* __restrict__ markers_rec,
     float* __restrict__ hand_rec, float* __restrict__ hand_normals, float* __restrict__ h2o_marker,
@@ -230,12 +234,15 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     __shared__ float red[GL_THREADS / 64][GL_NSUM];
     __shared__ float sbox[6 * (GL_THREADS / 64)];
     float* sNrm = sObj;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    // candidates in reverse launch order: the producer (skinning) wrote them in ascending order, so the most recently
+    // written vertices -- the ones still in the Infinity Cache -- are read first
+    const int b = gridDim.x - 1 - blockIdx.x, tid = threadIdx.x;
     const int H = tb.n_hand, M = tb.n_markers, NQ = H + M;
     const int Hpad = (H + NNF_CH - 1) / NNF_CH * NNF_CH;
     const float* vb = verts + (size_t)b * V * 3;
     const float* ob = obj + (size_t)b * O * 3;
     const float* onb = obj_n + (size_t)b * O * 3;
+    GL_T0();
 
     // ---- x -> y queries: lane owns hand vertices / markers q = tid + i*GL_THREADS, i < GL_NQ ------------------
     float qx[GL_NQ], qy[GL_NQ], qz[GL_NQ];
@@ -256,6 +263,7 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
             }
         }
     }
+    GL_T(0);
     // frames of the two clouds (block-wide bounding boxes) and the two tiles
     const NnfFrame fo = nnf_frame(ob, O, sbox, tid, GL_THREADS);
     const NnfFrame fh = nnf_frame_from_box(hlo, hhi, sbox, tid, GL_THREADS);
@@ -267,6 +275,7 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     }
     for (int q = H + tid; q < Hpad; q += GL_THREADS) nnf_store_point(sHand, q, NN_FAR, NN_FAR, NN_FAR, fh);
     __syncthreads();
+    GL_T(1);
 
     float sums[GL_NSUM];
 #pragma unroll
@@ -279,14 +288,18 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
 #pragma unroll
         for (int i = 0; i < GL_NQ; ++i) { cx[i] = qx[i] - fo.cx; cy[i] = qy[i] - fo.cy; cz[i] = qz[i] - fo.cz; }
         nnf_scan<GL_NQ>(sObj, Opad / NNF_CH, cx, cy, cz, m1, m2, m3, c1, c2);
+        GL_T(2);
         nnf_resolve<GL_NQ>(sObj, Opad / NNF_CH, fo, 0, cx, cy, cz, qx, qy, qz, m1, m3, c1, c2, best, bi);
+        GL_T(3);
 #pragma unroll
         for (int i = 0; i < GL_NQ; ++i) {
             const int q = tid + i * GL_THREADS;
             if (q >= NQ) continue;
             const float x = qx[i], y = qy[i], z = qz[i];
             const int k = bi[i];
-            const float dx = x - ob[k * 3], dy = y - ob[k * 3 + 1], dz = z - ob[k * 3 + 2];
+            float px, py, pz;
+            nnf_tile_point(sObj, fo, k, px, py, pz);           // bit-exact object point from the LDS tile
+            const float dx = x - px, dy = y - py, dz = z - pz;
             const float dist = sqrtf((dx * dx + dy * dy) + dz * dz);
             if (q < H) {
                 const float dot = (onb[k * 3] * dx + onb[k * 3 + 1] * dy) + onb[k * 3 + 2] * dz;
@@ -315,29 +328,19 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     // foot term: 0.1 * mean |z| (:173)
     for (int i = tid; i < tb.n_foot; i += GL_THREADS) sums[2] += fabsf(vb[tb.foot_ids[i] * 3 + 2]);
 
+    GL_T(4);
     // ---- hand normals (area-weighted, ascending face order) into the LDS space the object tile no longer needs ----
     __syncthreads();
     for (int i = tid; i < H; i += GL_THREADS) {
-        const int v = tb.hand_ids[i];
-        float nx = 0.f, ny = 0.f, nz = 0.f;
-        for (int e = vf_ptr[v]; e < vf_ptr[v + 1]; ++e) {
-            const int f = vf_idx[e];
-            const int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
-            const float ax = vb[i1 * 3] - vb[i0 * 3], ay = vb[i1 * 3 + 1] - vb[i0 * 3 + 1], az = vb[i1 * 3 + 2] - vb[i0 * 3 + 2];
-            const float bx = vb[i2 * 3] - vb[i0 * 3], by = vb[i2 * 3 + 1] - vb[i0 * 3 + 1], bz = vb[i2 * 3 + 2] - vb[i0 * 3 + 2];
-            nx += ay * bz - az * by;
-            ny += az * bx - ax * bz;
-            nz += ax * by - ay * bx;
-        }
-        const float sq = nx * nx + ny * ny + nz * nz;
-        if (sq > 0.f) { const float inv = 1.0f / sqrtf(sq); nx *= inv; ny *= inv; nz *= inv; }
-        if (isnan(nx)) { nx = 0.f; ny = 0.f; nz = 1.f; }
+        float nx, ny, nz;
+        saga_vertex_normal(vb, vf_ptr, vf_tri, tb.hand_ids[i], nx, ny, nz);
         sNrm[i * 3] = nx; sNrm[i * 3 + 1] = ny; sNrm[i * 3 + 2] = nz;
         float* dst = hand_normals + ((size_t)b * H + i) * 3;
         dst[0] = nx; dst[1] = ny; dst[2] = nz;
     }
     __syncthreads();
 
+    GL_T(5);
     // ---- y -> x : every object point finds its nearest HAND vertex (the marker direction is never used) ------
     for (int k0 = 0; k0 < O; k0 += GL_THREADS * GLF_NO) {
         float ox[GLF_NO], oy[GLF_NO], oz[GLF_NO], cx[GLF_NO], cy[GLF_NO], cz[GLF_NO], m1[GLF_NO], m2[GLF_NO], m3[GLF_NO], best[GLF_NO];
@@ -369,6 +372,7 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
         }
     }
 
+    GL_T(6);
     // ---- per-candidate means: wave shuffles, then the four wave partials in wave order ---------------------
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
@@ -495,12 +499,12 @@ extern "C" int saga_grasp_loss_fwd(const saga_model_t* m, const saga_grasp_table
                    "saga_grasp_loss_fwd: null buffer");
     void* prof = saga_prof_begin(SAGA_PROF_GRASP_FWD, stream);
     if (O <= GL_TILE)
-        grasp_loss_fwd_fast_kernel<<<B, GL_THREADS, 0, (hipStream_t)stream>>>(*tb, verts, m->faces, m->vf_ptr, m->vf_idx, obj,
+        grasp_loss_fwd_fast_kernel<<<B, GL_THREADS, 0, (hipStream_t)stream>>>(*tb, verts, m->vf_ptr, m->vf_tri, obj,
                                                                               obj_normals, markers_target, c_markers, c_object, terms,
                                                                               markers_rec, hand_rec, hand_normals, h2o_marker,
                                                                               h2o_signed, o2h_signed, idx_m2o, idx_h2o, idx_o2h, m->V, O);
     else
-        grasp_loss_fwd_kernel<<<B, GL_THREADS, 0, (hipStream_t)stream>>>(*tb, verts, m->faces, m->vf_ptr, m->vf_idx, obj, obj_normals,
+        grasp_loss_fwd_kernel<<<B, GL_THREADS, 0, (hipStream_t)stream>>>(*tb, verts, m->vf_ptr, m->vf_tri, obj, obj_normals,
                                                                          markers_target, c_markers, c_object, terms, markers_rec,
                                                                          hand_rec, hand_normals, h2o_marker, h2o_signed, o2h_signed,
                                                                          idx_m2o, idx_h2o, idx_o2h, m->V, O);

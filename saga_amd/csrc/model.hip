@@ -30,7 +30,7 @@ static int upload(T** dst, const std::vector<T>& src) {
 extern "C" void saga_model_destroy(saga_model_t* m) {
     if (!m) return;
     void* ptrs[] = {m->Bt, m->Bk, m->v_template, m->J_template, m->J_dirs, m->parents, m->depth, m->child_ptr,
-                    m->child_idx, m->w_idx, m->w_val, m->Wd, m->faces, m->vf_ptr, m->vf_idx, m->lmk_verts,
+                    m->child_idx, m->w_idx, m->w_val, m->Wd, m->faces, m->vf_ptr, m->vf_idx, m->vf_tri, m->lmk_verts,
                     m->lmk_bary, m->extra_verts};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -161,6 +161,10 @@ extern "C" int saga_model_create(saga_model_t** out, const saga_model_desc_t* d)
         std::vector<int32_t> fill(vptr.begin(), vptr.end() - 1);
         for (int f = 0; f < F; ++f)
             for (int c = 0; c < 3; ++c) vidx[fill[faces[f * 3 + c]]++] = f;
+        std::vector<int32_t> vtri((size_t)12 * F, 0);
+        for (size_t e = 0; e < (size_t)3 * F; ++e)
+            for (int c = 0; c < 3; ++c) vtri[e * 4 + c] = faces[(size_t)vidx[e] * 3 + c];
+        if ((rc = upload(&m->vf_tri, vtri))) goto fail;
         std::vector<int32_t> lv((size_t)3 * L);
         std::vector<float> lb(d->lmk_bary_host, d->lmk_bary_host + (size_t)3 * L);
         for (int l = 0; l < L; ++l)

@@ -6,35 +6,20 @@
 #include <math.h>
 
 #include "saga_common.h"
+#include "vertex_normal.h"
 
 void* saga_prof_begin(int id, void* stream);
 void saga_prof_end(void* scope);
 
-__global__ void vertex_normals_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces,
-                                      const int32_t* __restrict__ vf_ptr, const int32_t* __restrict__ vf_idx,
-                                      const int32_t* __restrict__ sel, int n_out, float* __restrict__ normals, int V) {
+__global__ void vertex_normals_kernel(const float* __restrict__ verts, const int32_t* __restrict__ vf_ptr,
+                                      const int32_t* __restrict__ vf_tri, const int32_t* __restrict__ sel, int n_out,
+                                      float* __restrict__ normals, int V) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (o >= n_out) return;
     const int v = sel ? sel[o] : o;
-    const float* vb = verts + (size_t)b * V * 3;
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    const int e0 = vf_ptr[v], e1 = vf_ptr[v + 1];
-    for (int e = e0; e < e1; ++e) {
-        const int f = vf_idx[e];
-        const int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
-        const float ax = vb[i1 * 3] - vb[i0 * 3], ay = vb[i1 * 3 + 1] - vb[i0 * 3 + 1], az = vb[i1 * 3 + 2] - vb[i0 * 3 + 2];
-        const float bx = vb[i2 * 3] - vb[i0 * 3], by = vb[i2 * 3 + 1] - vb[i0 * 3 + 1], bz = vb[i2 * 3 + 2] - vb[i0 * 3 + 2];
-        nx += ay * bz - az * by;
-        ny += az * bx - ax * bz;
-        nz += ax * by - ay * bx;
-    }
-    const float sq = nx * nx + ny * ny + nz * nz;
-    if (sq > 0.f) {
-        const float inv = 1.0f / sqrtf(sq);
-        nx *= inv; ny *= inv; nz *= inv;
-    }
-    if (isnan(nx)) { nx = 0.f; ny = 0.f; nz = 1.f; }
+    float nx, ny, nz;
+    saga_vertex_normal(verts + (size_t)b * V * 3, vf_ptr, vf_tri, v, nx, ny, nz);
     float* out = normals + ((size_t)b * n_out + o) * 3;
     out[0] = nx; out[1] = ny; out[2] = nz;
 }
@@ -46,7 +31,7 @@ static int launch(const saga_model_t* m, const float* verts, const int32_t* sel,
     SAGA_CHECK_ARG(verts && normals, "saga_vertex_normals: null argument");
     dim3 grid((n_out + 255) / 256, B);
     void* prof = saga_prof_begin(SAGA_PROF_NORMALS, stream);
-    vertex_normals_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(verts, m->faces, m->vf_ptr, m->vf_idx, sel, n_out, normals, m->V);
+    vertex_normals_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(verts, m->vf_ptr, m->vf_tri, sel, n_out, normals, m->V);
     saga_prof_end(prof);
     SAGA_LAUNCH_CHECK();
     return 0;

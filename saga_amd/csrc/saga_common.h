@@ -71,6 +71,7 @@ struct saga_model {
     int32_t* faces;     // [F,3]
     int32_t* vf_ptr;    // [V+1] CSR vertex -> incident (face, corner) in ascending face order
     int32_t* vf_idx;    // [3F]  face id
+    int32_t* vf_tri;    // [3F,4] the three vertex ids of that face (+ pad): one 16-B load per incidence entry
     int32_t* lmk_verts; // [L,3] vertex ids of each landmark's triangle
     float*   lmk_bary;  // [L,3]
     int32_t* extra_verts; // [E]

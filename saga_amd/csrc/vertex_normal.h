@@ -1,0 +1,42 @@
+// Area-weighted normal of vertex v (Open3D compute_vertex_normals convention, fittingop.py:158-164): sum of the
+// un-normalised cross products of its incident faces in ascending face order, normalised; zero stays zero, NaN -> (0,0,1).
+// The incidence list carries the three vertex ids of every face (one 16-B load), and the faces are fetched four at a
+// time (ids first, then all 36 coordinates) so that a vertex costs two memory round trips per four faces instead of
+// three per face; the sums are still taken face by face, in order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+__device__ __forceinline__ void saga_vertex_normal(const float* __restrict__ vb, const int32_t* __restrict__ vf_ptr,
+                                                   const int32_t* __restrict__ vf_tri, int v, float& ox, float& oy, float& oz) {
+#pragma clang fp contract(off)
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    const int e1 = vf_ptr[v + 1];
+    for (int e = vf_ptr[v]; e < e1; e += 4) {
+        int4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = reinterpret_cast<const int4*>(vf_tri)[min(e + u, e1 - 1)];
+        float p[4][9];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id[3] = {t[u].x, t[u].y, t[u].z};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                p[u][c * 3] = vb[id[c] * 3]; p[u][c * 3 + 1] = vb[id[c] * 3 + 1]; p[u][c * 3 + 2] = vb[id[c] * 3 + 2];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (e + u >= e1) break;
+            const float ax = p[u][3] - p[u][0], ay = p[u][4] - p[u][1], az = p[u][5] - p[u][2];
+            const float bx = p[u][6] - p[u][0], by = p[u][7] - p[u][1], bz = p[u][8] - p[u][2];
+            nx += ay * bz - az * by;
+            ny += az * bx - ax * bz;
+            nz += ax * by - ay * bx;
+        }
+    }
+    const float sq = nx * nx + ny * ny + nz * nz;
+    if (sq > 0.f) { const float inv = 1.0f / sqrtf(sq); nx *= inv; ny *= inv; nz *= inv; }
+    if (isnan(nx)) { nx = 0.f; ny = 0.f; nz = 1.f; }
+    ox = nx; oy = ny; oz = nz;
+}

@@ -14,5 +14,5 @@ for C in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTI
   i=$((i+1))
   timeout -s KILL 180 rocprofv3 --pmc $C -d $OUT/pmc$i -o p --output-format csv -- $PB > $OUT/bench_pmc$i.json 2> $OUT/pmc$i.err || { echo "pmc pass $i failed"; tail -3 $OUT/pmc$i.err; exit 1; }
 done
-python3 $PWD/scripts/summarize_pmc.py $OUT > $OUT/summary.txt
+python3 $PWD/scripts/summarize_pmc.py $OUT > /dev/null
 tail -40 $OUT/summary.txt

@@ -1,34 +1,71 @@
 #!/usr/bin/env python3
-"""Aggregate rocprofv3 output of scripts/profile_round.sh: per kernel, mean duration and mean counter values per launch
-(library kernels only; torch's element-wise kernels are summed into one line)."""
-import csv, glob, os, sys, collections
+"""Aggregate rocprofv3 output of scripts/profile_round.sh: per kernel (name + grid size), mean duration and mean counter
+values per launch.  Writes <dir>/summary.txt (human) and <dir>/summary.json (read by bench.py for `roofline.traffic`).
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md 'HBM': FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of
+1024 B by rocprofv3; on gfx950 FETCH_SIZE counts 128-B read requests as 64 B, so reads are doubled; WRITE_SIZE is exact
+for streaming stores.  Separate --pmc passes (one per counter group)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
 root = sys.argv[1]
 csv.field_size_limit(1 << 30)
+OURS = ('gemm_nt', 'skin_', 'pose_', 'joints_', 'grasp_loss', 'nn_scan', 'nn_fast', 'vertex_normals', 'cont6d', 'rodrigues',
+        'params_', 'loss_sum', 'adam_', 'best_update')
+
 
 def short(name):
-    n = name.split('(')[0]
-    return n.replace('void ', '').strip()
+    return name.split('(')[0].replace('void ', '').strip()
 
-OURS = ('gemm_nt', 'skin_', 'pose_', 'joints_', 'grasp_loss', 'nn_scan', 'vertex_normals', 'cont6d', 'rodrigues', 'fit_', 'adam', 'param')
+
 dur = collections.defaultdict(list)
 for f in glob.glob(os.path.join(root, 'trace', '**', '*kernel_trace.csv'), recursive=True):
     for r in csv.DictReader(open(f)):
         k = short(r['Kernel_Name'])
-        if not k.startswith(OURS):
+        if k.startswith(OURS):
+            k = '%s grid=%s' % (k, int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z']))
+        else:
             k = '(other: torch / rocBLAS kernels)'
         dur[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-print('== kernel trace: launches, mean us, total ms')
-for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-    print('%-60s %6d %10.1f %10.2f' % (k, len(v), sum(v) / len(v), sum(v) / 1e3))
 cnt = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, 'pmc*', '**', '*counter_collection.csv'), recursive=True):
     for r in csv.DictReader(open(f)):
         k = short(r['Kernel_Name'])
         if not k.startswith(OURS):
             continue
-        cnt[k][r['Counter_Name']].append(float(r['Counter_Value']))
-print('== PMC: mean per launch')
+        cnt['%s grid=%s' % (k, r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
+
+out = {}
+lines = ['== kernel trace: launches, mean us, total ms']
+for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+    lines.append('%-64s %6d %10.1f %10.2f' % (k, len(v), sum(v) / len(v), sum(v) / 1e3))
+    out[k] = {'launches': len(v), 'mean_us': sum(v) / len(v)}
+lines.append('== PMC: mean per launch (+ derived: HBM bytes per the guide, MFMA / VALU utilisation)')
 for k in sorted(cnt):
-    print(k)
-    for c, v in sorted(cnt[k].items()):
-        print('    %-32s %18.1f   (n=%d)' % (c, sum(v) / len(v), len(v)))
+    c = {n: sum(v) / len(v) for n, v in cnt[k].items()}
+    d = out.setdefault(k, {})
+    d['counters'] = c
+    if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+        d['hbm_read_bytes'] = 2.0 * c['FETCH_SIZE'] * 1024.0       # gfx950: 128-B requests tallied at 64 B
+        d['hbm_write_bytes'] = c['WRITE_SIZE'] * 1024.0
+        d['hbm_bytes'] = d['hbm_read_bytes'] + d['hbm_write_bytes']
+    if c.get('GRBM_GUI_ACTIVE'):
+        cyc = c['GRBM_GUI_ACTIVE'] / 8.0                            # summed over the 8 XCDs
+        d['gpu_cycles'] = cyc
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in c:
+            d['mfma_util'] = c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / cyc      # 1024 SIMDs
+        if 'SQ_ACTIVE_INST_VALU' in c:
+            d['valu_issue_util'] = c['SQ_ACTIVE_INST_VALU'] * 4.0 / 1024.0 / cyc   # quad-cycles per SIMD
+    lines.append(k)
+    for n, v in sorted(c.items()):
+        lines.append('    %-32s %18.1f' % (n, v))
+    for n in ('hbm_bytes', 'mfma_util', 'valu_issue_util'):
+        if n in d:
+            lines.append('    -> %-29s %18.4g' % (n, d[n]))
+open(os.path.join(root, 'summary.txt'), 'w').write('\n'.join(lines) + '\n')
+json.dump(out, open(os.path.join(root, 'summary.json'), 'w'), indent=1, sort_keys=True)
+print('\n'.join(lines))
