@@ -42,13 +42,16 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // EPI 2: C[row][col] = leaky_relu(acc + bias[col], 0.2)                    (VPoser decoder layers, fit_step.hip)
 // EPI 3: C[row][col] = acc * (aux[row][col] > 0 ? 1 : 0.2)                 (their backward; aux = the layer's output)
 // BKT  : k-depth of one LDS tile (16 or 32); NST: LDS stages (NST-1 tiles in flight beside the one being multiplied)
-template <int EPI, int BKT, int NST>
+// WT   : 32x32 MFMA tiles per wave and dimension: 2 -> 128x128 block tile (the blend contraction), 1 -> 64x64 (the small
+//        decoder layers, which need 4x the blocks to fill 256 CUs)
+template <int EPI, int BKT, int NST, int WT = 2>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ Bt, int ldb, float* __restrict__ C,
                                                           int ldc, const float* __restrict__ bias,
                                                           const float* __restrict__ aux, int M, int N, int K,
                                                           int kchunk, int tiles_m) {
-    constexpr int TILE_FLOATS = BM * BKT;            // one operand tile
+    constexpr int TBM = 64 * WT, TBN = 64 * WT;      // block tile
+    constexpr int TILE_FLOATS = TBM * BKT;           // one operand tile
     constexpr int PPW = TILE_FLOATS * 4 / 1024 / 4;  // 1-KiB LDS-DMA pieces per wave per operand tile: 4 (BKT 32) / 2 (16)
     constexpr int RPP = 1024 / (BKT * 4);            // tile rows per piece: 8 / 16
     constexpr int CPR = BKT / 4;                     // 16-B chunks per row: 8 / 4
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     // consecutive blocks walk M first so the (large, batch-shared) Bt tile stays hot in L2 while A is re-read
     const int tile_m = blockIdx.x % tiles_m;
     const int tile_n = blockIdx.x / tiles_m;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = tile_m * TBM, n0 = tile_n * TBN;
     const int k_begin = blockIdx.z * kchunk;
     const int k_end = min(K, k_begin + kchunk);
     const int T = (k_end - k_begin) / BKT;
@@ -93,17 +96,17 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[WT][WT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // fragment read offsets (floats): row * BKT + ((2g + half) ^ swz(row)) * 4; swz(row) depends on l31 only
     const int fsw = swz(l31);
-    const int a_row = (wm * 64 + l31) * BKT, b_row = (wn * 64 + l31) * BKT;
+    const int a_row = (wm * 32 * WT + l31) * BKT, b_row = (wn * 32 * WT + l31) * BKT;
 
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
@@ -117,12 +120,12 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
         const float* Bs = As + TILE_FLOATS;
         // all fragment reads of this k-tile first, THEN the LDS-DMA of a later tile: hipcc waits vmcnt(0) before any
         // ds_read that follows an outstanding LDS-DMA in program order, which would serialise the prefetch with the MFMAs
-        float4 af[BKT / 8][2], bf[BKT / 8][2];
+        float4 af[BKT / 8][WT], bf[BKT / 8][WT];
 #pragma unroll
         for (int g = 0; g < BKT / 8; ++g) {
             const int koff = ((2 * g + half) ^ fsw) * 4;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < WT; ++u) {
                 af[g][u] = *reinterpret_cast<const float4*>(As + a_row + u * 32 * BKT + koff);
                 bf[g][u] = *reinterpret_cast<const float4*>(Bs + b_row + u * 32 * BKT + koff);
             }
@@ -133,9 +136,9 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
 #pragma unroll
         for (int g = 0; g < BKT / 8; ++g) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < WT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
+                for (int nt = 0; nt < WT; ++nt) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].x, bf[g][nt].x, acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].y, bf[g][nt].y, acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].z, bf[g][nt].z, acc[mt][nt], 0, 0, 0);
@@ -147,10 +150,10 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* Cz = C;
     if (EPI == 1) Cz += (size_t)blockIdx.z * M * ldc;
-    const bool full = (m0 + BM <= M);       // N is always a multiple of BN here (Npad / 512)
+    const bool full = (m0 + TBM <= M);       // N is always a multiple of BN here (Npad / 512)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int col = n0 + wn * 64 + nt * 32 + l31;
+    for (int nt = 0; nt < WT; ++nt) {
+        const int col = n0 + wn * 32 * WT + nt * 32 + l31;
         if (col >= N) continue;
         const float bv = ((EPI == 0 || EPI == 2) && bias) ? bias[col] : 0.f;
         auto epi = [&](float v, size_t off) -> float {
@@ -159,8 +162,8 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
             return v;
         };
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const size_t cbase = (size_t)(m0 + wm * 64 + mt * 32 + 4 * half) * ldc + col;
+        for (int mt = 0; mt < WT; ++mt) {
+            const size_t cbase = (size_t)(m0 + wm * 32 * WT + mt * 32 + 4 * half) * ldc + col;
             if (full) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int row = m0 + wm * 32 * WT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     if (row < M) Cz[(size_t)row * ldc + col] = epi(acc[mt][nt][r] + bv, (size_t)row * ldc + col);
                 }
             }
@@ -199,19 +202,19 @@ int saga_launch_blend_bwd(const saga_model* m, const float* g_vposed, float* sla
     return 0;
 }
 
-// Small dense layers of the parameter decoder (fit_step.hip): C[M,N] = epi(A[M,K] . Bt[N,K]^T).  N a multiple of 128,
+// Small dense layers of the parameter decoder (fit_step.hip): C[M,N] = epi(A[M,K] . Bt[N,K]^T), 64x64 block tiles.  N a multiple of 64,
 // K a multiple of 16, rows of A and Bt 16-B aligned.
 int saga_launch_gemm_nt(int epi, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, const float* bias,
                         const float* aux, int M, int N, int K, hipStream_t st) {
-    SAGA_CHECK_ARG(N % BN == 0 && K % GEMM_BKT == 0 && lda % 4 == 0 && ldb % 4 == 0 && M > 0, "gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
+    SAGA_CHECK_ARG(N % 64 == 0 && K % GEMM_BKT == 0 && lda % 4 == 0 && ldb % 4 == 0 && M > 0, "gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
+    const int tiles_m = (M + 63) / 64, tiles_n = N / 64;
     dim3 grid(tiles_m * tiles_n, 1, 1);
     if (epi == 0)
-        gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD><<<grid, 256, 0, st>>>(A, lda, Bt, ldb, C, ldc, bias, aux, M, N, K, K, tiles_m);
+        gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD, 1><<<grid, 256, 0, st>>>(A, lda, Bt, ldb, C, ldc, bias, aux, M, N, K, K, tiles_m);
     else if (epi == 2)
-        gemm_nt_f32_kernel<2, GEMM_BKT, GEMM_NST_FWD><<<grid, 256, 0, st>>>(A, lda, Bt, ldb, C, ldc, bias, aux, M, N, K, K, tiles_m);
+        gemm_nt_f32_kernel<2, GEMM_BKT, GEMM_NST_FWD, 1><<<grid, 256, 0, st>>>(A, lda, Bt, ldb, C, ldc, bias, aux, M, N, K, K, tiles_m);
     else if (epi == 3)
-        gemm_nt_f32_kernel<3, GEMM_BKT, GEMM_NST_FWD><<<grid, 256, 0, st>>>(A, lda, Bt, ldb, C, ldc, bias, aux, M, N, K, K, tiles_m);
+        gemm_nt_f32_kernel<3, GEMM_BKT, GEMM_NST_FWD, 1><<<grid, 256, 0, st>>>(A, lda, Bt, ldb, C, ldc, bias, aux, M, N, K, K, tiles_m);
     else
         SAGA_CHECK_ARG(false, "gemm_nt: unknown epilogue %d", epi);
     SAGA_LAUNCH_CHECK();

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     }
 }
 
-// grad_vertices [B,V,3] (pre-zeroed) from the upstream gradients of the eight differentiable terms
+// grad_vertices [B,V,3] (zero-filled here, then the touched vertices) from the upstream gradients of the eight differentiable terms
 __global__ __launch_bounds__(GL_BWD_THREADS) void grasp_loss_bwd_kernel(
     saga_grasp_tables_t tb, const float* __restrict__ g_terms, const float* __restrict__ verts,
     const float* __restrict__ obj, const float* __restrict__ mk_target, const float* __restrict__ c_mk,
@@ -416,6 +416,17 @@ __global__ __launch_bounds__(GL_BWD_THREADS) void grasp_loss_bwd_kernel(
     const float* vb = verts + (size_t)b * V * 3;
     const float* ob = obj + (size_t)b * O * 3;
     for (int i = tid; i < U * 3; i += GL_BWD_THREADS) acc[i] = 0.f;
+    {   // zero-fill this candidate's row of the dense gradient (no separate memset pass): scalar head up to 16-B
+        // alignment, float4 body, scalar tail; the scatter below comes after a barrier
+        float* gb0 = g_verts + (size_t)b * V * 3;
+        const int n = V * 3;
+        const int head = min(n, (int)((16 - ((uintptr_t)gb0 & 15)) & 15) >> 2);
+        const int body = (n - head) >> 2;
+        if (tid < head) gb0[tid] = 0.f;
+        float4* g4 = reinterpret_cast<float4*>(gb0 + head);
+        for (int i = tid; i < body; i += GL_BWD_THREADS) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = head + body * 4 + tid; i < n; i += GL_BWD_THREADS) gb0[i] = 0.f;
+    }
     __syncthreads();
     // markers: L1 reconstruction + contact-weighted distance to the nearest object point
     for (int p = tid; p < M; p += GL_BWD_THREADS) {
@@ -528,9 +539,8 @@ extern "C" int saga_grasp_loss_bwd(const saga_model_t* m, const saga_grasp_table
                    "saga_grasp_loss_bwd: null buffer");
     hipStream_t st = (hipStream_t)stream;
     void* prof = saga_prof_begin(SAGA_PROF_GRASP_BWD, stream);
-    hipError_t e = hipMemsetAsync(g_verts, 0, (size_t)B * m->V * 3 * sizeof(float), st);
-    if (e == hipSuccess)
-        grasp_loss_bwd_kernel<<<B, GL_BWD_THREADS, 0, st>>>(*tb, g_terms, verts, obj, markers_target, c_markers, c_object, markers_rec,
+    hipError_t e = hipSuccess;
+    grasp_loss_bwd_kernel<<<B, GL_BWD_THREADS, 0, st>>>(*tb, g_terms, verts, obj, markers_target, c_markers, c_object, markers_rec,
                                                         hand_rec, h2o_signed, o2h_signed, idx_m2o, idx_h2o, idx_o2h, g_verts, m->V, O);
     saga_prof_end(prof);
     SAGA_HIP(e);

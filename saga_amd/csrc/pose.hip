@@ -208,9 +208,23 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void pose_bwd_kernel(
     __shared__ float s_rel[WAVES_PER_BLOCK][NJ * 3];
     __shared__ float s_dJ[WAVES_PER_BLOCK][NJ * 3];
     __shared__ float s_drel[WAVES_PER_BLOCK][NJ * 3];
+    __shared__ __attribute__((aligned(16))) float s_gfeat[WAVES_PER_BLOCK][FEAT_K];   // split-K slabs summed (slab order)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.x * WAVES_PER_BLOCK + wave;
     const bool live = b < B;
+    if (live && has_verts) {
+        // grad of feat = sum of the split-K slabs: the wave reads each slab row as 2 KB of coalesced float4s
+        // (lane owns columns 4*lane..+3 and 256+4*lane..+3); every lane then picks its 9 columns from LDS
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        for (int s = 0; s < n_slabs; ++s) {
+            const float4* row = reinterpret_cast<const float4*>(slabs + ((size_t)s * B + b) * FEAT_K);
+            const float4 u = row[lane], v = row[64 + lane];
+            a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+            a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
+        }
+        reinterpret_cast<float4*>(s_gfeat[wave])[lane] = a0;
+        reinterpret_cast<float4*>(s_gfeat[wave])[64 + lane] = a1;
+    }
     const int j = lane;
     const bool own = live && j < NJ;
 
@@ -308,11 +322,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void pose_bwd_kernel(
         // add the direct pose-feature gradient (pose_feat = vec(R_j - I), j >= 1), summed over the split-K slabs
         if (j >= 1 && has_verts) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                float acc = 0.f;
-                for (int s = 0; s < n_slabs; ++s) acc += slabs[((size_t)s * B + b) * FEAT_K + S + (j - 1) * 9 + k];
-                dR[k] += acc;
-            }
+            for (int k = 0; k < 9; ++k) dR[k] += s_gfeat[wave][S + (j - 1) * 9 + k];
         }
         float r[3], gr[3];
 #pragma unroll
@@ -327,9 +337,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void pose_bwd_kernel(
     if (live) {
         // g_shape[s] = slab-sum(feat grad)[s] + sum_{j,c} dJ[j,c] * J_dirs[s, j*3+c]
         if (lane < S) {
-            float acc = 0.f;
-            if (has_verts)
-                for (int s = 0; s < n_slabs; ++s) acc += slabs[((size_t)s * B + b) * FEAT_K + lane];
+            float acc = has_verts ? s_gfeat[wave][lane] : 0.f;
             for (int q = 0; q < NJ * 3; ++q) acc = fmaf(s_dJ[wave][q], J_dirs[lane * (NJ * 3) + q], acc);
             g_shape[(size_t)b * S + lane] = acc;
         }
