@@ -80,7 +80,7 @@ __global__ __launch_bounds__(NTH) void nn_fast_kernel(const float* __restrict__ 
     float m1[NQ], m2[NQ], m3[NQ], best[NQ];
     int c1[NQ], c2[NQ], bi[NQ];
     nnf_scan<NQ>(sdb, cnt_pad / NNF_CH, qx, qy, qz, m1, m2, m3, c1, c2);
-    nnf_resolve<NQ>(sdb, cnt_pad / NNF_CH, f, 0, qx, qy, qz, ox, oy, oz, m1, m3, c1, c2, best, bi);
+    nnf_resolve<NQ>(sdb, cnt_pad / NNF_CH, f, 0, qx, qy, qz, ox, oy, oz, m1, m2, m3, c1, c2, best, bi);
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const int p = q0 + tid + i * NTH;

@@ -185,20 +185,25 @@ __device__ __forceinline__ void nnf_scan(const float* __restrict__ s, int n_chun
     }
 }
 
-// exact evaluation of one chunk for one query (original coordinates o*), index order, strict '<'
+// exact evaluation of one chunk for one query (original coordinates o*), index order, strict '<'.  Two points per packed
+// instruction; every packed lane performs the IEEE operation of nn_dist2, so the values are those of the scalar chain.
 __device__ __forceinline__ void nnf_exact_chunk(const float* __restrict__ s, const NnfFrame& f, int ch, int base, float ox, float oy,
                                                 float oz, float& best, int& bi) {
+#pragma clang fp contract(off)
     const float4* t = reinterpret_cast<const float4*>(s + ch * NNF_CSTRIDE);
+    const nn_f2 mh = {-0.5f, -0.5f}, cx = {f.cx, f.cx}, cy = {f.cy, f.cy}, cz = {f.cz, f.cz};
+    const nn_f2 qx = {ox, ox}, qy = {oy, oy}, qz = {oz, oz};
 #pragma unroll
     for (int g = 0; g < NNF_CH / 2; ++g) {
         const float4 a = t[2 * g], b = t[2 * g + 1];
-        const float x0 = __builtin_fmaf(-0.5f, a.x, f.cx), y0 = __builtin_fmaf(-0.5f, a.z, f.cy), z0 = __builtin_fmaf(-0.5f, b.x, f.cz);
-        const float x1 = __builtin_fmaf(-0.5f, a.y, f.cx), y1 = __builtin_fmaf(-0.5f, a.w, f.cy), z1 = __builtin_fmaf(-0.5f, b.y, f.cz);
-        const float d0 = nn_dist2(ox, oy, oz, x0, y0, z0);
-        const float d1 = nn_dist2(ox, oy, oz, x1, y1, z1);
+        const nn_f2 X = {a.x, a.y}, Y = {a.z, a.w}, Z = {b.x, b.y};
+        const nn_f2 px = __builtin_elementwise_fma(mh, X, cx), py = __builtin_elementwise_fma(mh, Y, cy),
+                    pz = __builtin_elementwise_fma(mh, Z, cz);                          // original coordinates, bit-exact
+        const nn_f2 dx = qx - px, dy = qy - py, dz = qz - pz;
+        const nn_f2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
         const int k = base + ch * NNF_CH + 2 * g;
-        if (d0 < best) { best = d0; bi = k; }
-        if (d1 < best) { best = d1; bi = k + 1; }
+        if (d.x < best) { best = d.x; bi = k; }
+        if (d.y < best) { best = d.y; bi = k + 1; }
     }
 }
 
@@ -208,7 +213,8 @@ template <int NQ>
 __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_chunks, const NnfFrame& f, int base,
                                             const float (&qx)[NQ], const float (&qy)[NQ], const float (&qz)[NQ],
                                             const float (&ox)[NQ], const float (&oy)[NQ], const float (&oz)[NQ],
-                                            const float (&m1)[NQ], const float (&m3)[NQ], const int (&c1)[NQ], const int (&c2)[NQ],
+                                            const float (&m1)[NQ], const float (&m2)[NQ], const float (&m3)[NQ],
+                                            const int (&c1)[NQ], const int (&c2)[NQ],
                                             float (&best)[NQ], int (&bi)[NQ]) {
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -218,10 +224,12 @@ __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_c
         best[i] = INFINITY; bi[i] = 0;
         if (m3[i] > thr) {
             // the exact winner is in chunk c1 or c2: lower chunk first so that ties keep the lowest index
-            const int a = c2[i] < 0 ? c1[i] : min(c1[i], c2[i]);
-            const int b = c2[i] < 0 ? c1[i] : max(c1[i], c2[i]);
+            // (c2 only matters when its minimum is inside the margin)
+            const bool two = c2[i] >= 0 && m2[i] <= thr;
+            const int a = two ? min(c1[i], c2[i]) : c1[i];
+            const int b = two ? max(c1[i], c2[i]) : c1[i];
             nnf_exact_chunk(s, f, a, base, ox[i], oy[i], oz[i], best[i], bi[i]);
-            nnf_exact_chunk(s, f, b, base, ox[i], oy[i], oz[i], best[i], bi[i]);
+            if (b != a) nnf_exact_chunk(s, f, b, base, ox[i], oy[i], oz[i], best[i], bi[i]);
         } else {
             // slow path: every chunk whose approximate minimum is inside the margin, in index order
             for (int c = 0; c < n_chunks; ++c) {

@@ -239,7 +239,8 @@ __global__ __launch_bounds__(SKIN_THREADS) void skin_bwd_vposed_kernel(const flo
 // Block = 4 waves, each wave reduces a quarter of the vertex range; partials are combined through LDS in wave order.
 #define DA_CANDS 4
 #define DA_STEP 16      // vertices per wave per iteration: 4 k-steps of v_mfma_f32_16x16x4_f32
-#define DA_XSTRIDE (DA_STEP * 8 + 8)   // floats per candidate plane of a staging tile (+8: no bank conflict between planes)
+#define DA_XSTRIDE (DA_STEP * 8 + 16)  // floats per candidate plane of a staging tile: = 16 mod 32, so the A-operand reads of the two
+                                       // candidates of an MFMA tile (offsets kq*8 + 0..6) fall on disjoint banks
 
 // FUSE (compressed weight table with exactly 4 entries per vertex): the same pass also produces
 // g_v_posed[b,v] = T_v^T g[b,v] (part 1 above) from the rows it has already fetched -- its VALU work hides under the MFMAs
