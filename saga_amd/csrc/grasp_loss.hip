@@ -407,7 +407,13 @@ __global__ __launch_bounds__(GL_BWD_THREADS) void grasp_loss_bwd_kernel(
     const float* __restrict__ c_obj, const float* __restrict__ markers_rec, const float* __restrict__ hand_rec,
     const float* __restrict__ h2o_signed, const float* __restrict__ o2h_signed, const int32_t* __restrict__ idx_m2o,
     const int32_t* __restrict__ idx_h2o, const int32_t* __restrict__ idx_o2h, float* __restrict__ g_verts, int V, int O) {
-    __shared__ float acc[GL_MAX_UNIQUE * 3];
+    // Accumulators are 64-bit fixed point (2^-40 units, range +-2^23): integer adds are associative, so the scatter-add of
+    // many object points into one hand vertex gives the same bits whatever order the LDS atomics land in, and the sum is
+    // the exactly rounded one (float atomics would make the whole iteration run-to-run irreproducible).
+    __shared__ unsigned long long acc[GL_MAX_UNIQUE * 3];
+    auto add_fx = [](unsigned long long* p, float v) {
+        atomicAdd(p, (unsigned long long)__float2ll_rn(v * 1099511627776.0f));
+    };
     const int b = blockIdx.x, tid = threadIdx.x;
     const int H = tb.n_hand, M = tb.n_markers, U = tb.n_unique;
     const float* gt = g_terms + (size_t)b * NT;
@@ -415,7 +421,7 @@ __global__ __launch_bounds__(GL_BWD_THREADS) void grasp_loss_bwd_kernel(
                 g_ocol = gt[7];
     const float* vb = verts + (size_t)b * V * 3;
     const float* ob = obj + (size_t)b * O * 3;
-    for (int i = tid; i < U * 3; i += GL_BWD_THREADS) acc[i] = 0.f;
+    for (int i = tid; i < U * 3; i += GL_BWD_THREADS) acc[i] = 0ull;
     {   // zero-fill this candidate's row of the dense gradient (no separate memset pass): scalar head up to 16-B
         // alignment, float4 body, scalar tail; the scatter below comes after a barrier
         float* gb0 = g_verts + (size_t)b * V * 3;
@@ -437,15 +443,15 @@ __global__ __launch_bounds__(GL_BWD_THREADS) void grasp_loss_bwd_kernel(
         const float n = sqrtf(dx * dx + dy * dy + dz * dz);
         const float w = n > 0.f ? g_mc * c_mk[(size_t)b * M + p] / ((float)M * n) : 0.f;
         const float wr = g_rec / (float)(M * 3) + (p < tb.n_body_markers ? g_brec / (float)(tb.n_body_markers * 3) : 0.f);
-        float* a = acc + tb.marker_slot[p] * 3;
-        atomicAdd(a + 0, wr * sgn(m[0] - tg[0]) + w * dx);
-        atomicAdd(a + 1, wr * sgn(m[1] - tg[1]) + w * dy);
-        atomicAdd(a + 2, wr * sgn(m[2] - tg[2]) + w * dz);
+        unsigned long long* a = acc + tb.marker_slot[p] * 3;
+        add_fx(a + 0, wr * sgn(m[0] - tg[0]) + w * dx);
+        add_fx(a + 1, wr * sgn(m[1] - tg[1]) + w * dy);
+        add_fx(a + 2, wr * sgn(m[2] - tg[2]) + w * dz);
     }
     // foot: 0.1 * mean |z|
     for (int f = tid; f < tb.n_foot; f += GL_BWD_THREADS) {
         const float z = vb[tb.foot_ids[f] * 3 + 2];
-        atomicAdd(acc + tb.foot_slot[f] * 3 + 2, g_foot * 0.1f * sgn(z) / (float)tb.n_foot);
+        add_fx(acc + tb.foot_slot[f] * 3 + 2, g_foot * 0.1f * sgn(z) / (float)tb.n_foot);
     }
     // hand -> object: |d_h| weighted by the prior-contact / collision masks (masks carry no gradient)
     for (int p = tid; p < H; p += GL_BWD_THREADS) {
@@ -459,8 +465,8 @@ __global__ __launch_bounds__(GL_BWD_THREADS) void grasp_loss_bwd_kernel(
             const int k = idx_h2o[(size_t)b * H + p];
             const float dx = h[0] - ob[k * 3], dy = h[1] - ob[k * 3 + 1], dz = h[2] - ob[k * 3 + 2];
             const float w = coef / sqrtf(dx * dx + dy * dy + dz * dz);
-            float* a = acc + tb.hand_slot[p] * 3;
-            atomicAdd(a + 0, w * dx); atomicAdd(a + 1, w * dy); atomicAdd(a + 2, w * dz);
+            unsigned long long* a = acc + tb.hand_slot[p] * 3;
+            add_fx(a + 0, w * dx); add_fx(a + 1, w * dy); add_fx(a + 2, w * dz);
         }
     }
     // object -> hand: gradient lands on the nearest hand vertex (scatter-add; many object points share one vertex)
@@ -472,13 +478,13 @@ __global__ __launch_bounds__(GL_BWD_THREADS) void grasp_loss_bwd_kernel(
             const float* h = hand_rec + ((size_t)b * H + j) * 3;
             const float dx = ob[k * 3] - h[0], dy = ob[k * 3 + 1] - h[1], dz = ob[k * 3 + 2] - h[2];
             const float w = -coef / sqrtf(dx * dx + dy * dy + dz * dz);
-            float* a = acc + tb.hand_slot[j] * 3;
-            atomicAdd(a + 0, w * dx); atomicAdd(a + 1, w * dy); atomicAdd(a + 2, w * dz);
+            unsigned long long* a = acc + tb.hand_slot[j] * 3;
+            add_fx(a + 0, w * dx); add_fx(a + 1, w * dy); add_fx(a + 2, w * dz);
         }
     }
     __syncthreads();
     float* gb = g_verts + (size_t)b * V * 3;
-    for (int i = tid; i < U * 3; i += GL_BWD_THREADS) gb[tb.unique_ids[i / 3] * 3 + (i % 3)] = acc[i];
+    for (int i = tid; i < U * 3; i += GL_BWD_THREADS) gb[tb.unique_ids[i / 3] * 3 + (i % 3)] = (float)((double)(long long)acc[i] * 9.094947017729282e-13);
 }
 
 static int check_tables(const saga_grasp_tables_t* tb) {

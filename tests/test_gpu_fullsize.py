@@ -1,0 +1,100 @@
+"""Parity at BASELINE.json's full size (B = 4096 candidates x 2,048 object points), where the CPU oracle is too slow:
+size-independent properties instead -- a candidate's iteration does not depend on the batch it sits in (bit for bit),
+and the fused loss finds the same neighbours as the stand-alone exact chamfer scan on every one of the ~12 M queries."""
+import numpy as np
+import pytest
+import torch
+
+from saga_amd.synthetic import make_candidate_params, make_grasp_targets, make_object_cloud
+
+pytestmark = pytest.mark.gpu
+B_FULL, O = 4096, 2048
+
+
+def _op(body_model_dir, B):
+    from saga_amd.fitting import FittingOP
+    from saga_amd.vposer import VPoserDecoder
+    op = FittingOP({'batch_size': B, 'device': 'cuda', 'body_model_path': body_model_dir, 'vposer': VPoserDecoder(seed=0),
+                    'genders': ('male',), 'verbose': False})
+    op.bm = op.bm_male
+    return op
+
+
+def _inputs(B):
+    vo, no, _, _ = make_object_cloud(B, n_points=O, seed=0)
+    mk, mc, oc = make_grasp_targets(B, vo, seed=4815)
+    return make_candidate_params(B, seed=1234, scale=0.3), dict(mk=mk, mc=mc, oc=oc, vo=vo, no=no)
+
+
+def test_candidates_are_independent_at_full_batch(body_model_dir):
+    var, d = _inputs(B_FULL)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    big = _op(body_model_dir, B_FULL)
+    big.set_variables(var)
+    prob = big.make_problem(cu(d['mk']), cu(d['vo']), cu(d['no']), cu(d['oc']), cu(d['mc']))
+    terms = torch.zeros(B_FULL, 16, device='cuda')
+    for _ in range(2):
+        loss_big, mk_big = big.native_step(2, prob, terms)
+    sel = np.array([0, 3, 130, 1001, 2047, 2048, 4000, 4095])
+    small = _op(body_model_dir, len(sel))
+    small.set_variables({k: v[sel] for k, v in var.items()})
+    ps = small.make_problem(*(cu(d[k][sel]) for k in ('mk', 'vo', 'no', 'oc', 'mc')))
+    ts = torch.zeros(len(sel), 16, device='cuda')
+    for _ in range(2):
+        loss_s, mk_s = small.native_step(2, ps, ts)
+    idx = torch.from_numpy(sel).cuda()
+    assert torch.equal(loss_big[idx], loss_s)
+    assert torch.equal(mk_big[idx], mk_s)
+    assert torch.equal(terms[idx], ts)
+    assert torch.equal(big.vars[idx], small.vars)             # the Adam update too
+    assert torch.isfinite(loss_big).all()
+
+
+def test_fused_loss_neighbours_equal_exact_chamfer_at_full_batch(body_model_dir):
+    import saga_amd.chamfer_distance as chd
+    from saga_amd import _lib
+    var, d = _inputs(B_FULL)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    op = _op(body_model_dir, B_FULL)
+    op.set_variables(var)
+    prob = op.make_problem(cu(d['mk']), cu(d['vo']), cu(d['no']), cu(d['oc']), cu(d['mc']))
+    op.native_step(2, prob)
+    H, M = op.tables.n_hand, op.tables.n_markers
+    verts = op.workspace_view('vertices', O, (B_FULL, op.bm.num_verts, 3))
+    hand = verts[:, op.rhand_verts].contiguous()
+    markers = verts[:, op.markers_143].contiguous()
+    obj = prob['obj']
+    d1, d2, i1, i2 = chd.ChamferDistance(hand, obj)            # two-level scan (single-tile database)
+    assert torch.equal(op.workspace_view('idx_h2o', O, (B_FULL, H), torch.int32), i1)
+    assert torch.equal(op.workspace_view('idx_o2h', O, (B_FULL, O), torch.int32), i2)
+    _, _, im, _ = chd.ChamferDistance(markers, obj)
+    assert torch.equal(op.workspace_view('idx_m2o', O, (B_FULL, M), torch.int32), im)
+    # and against the multi-tile exact 6-op scan (databases > 2048 points take that kernel): pad the object cloud with
+    # far-away points so the same neighbours must come out of the other code path
+    far = torch.full((B_FULL, 64, 3), 1.0e3, device='cuda')
+    _, _, i1x, _ = chd.ChamferDistance(hand, torch.cat([obj, far], 1))
+    assert torch.equal(i1x, i1)
+    # distances are the exact fp32 chain of the winner
+    g = obj.gather(1, i1.long()[..., None].expand(-1, -1, 3))
+    dx, dy, dz = (hand - g).unbind(-1)
+    ref = torch.addcmul(torch.addcmul(dx * dx, dy, dy), dz, dz)      # fma(dz,dz,fma(dy,dy,dx*dx)) up to fusion
+    assert torch.allclose(d1, ref, rtol=1e-6, atol=0)
+
+
+def test_pose_opt_writes_reference_schema(body_model_dir, tmp_path):
+    from saga_amd.fitting import FittingOP
+    from saga_amd.opt_grasppose import pose_opt
+    from saga_amd.vposer import VPoserDecoder
+    n, k = 2, 3
+    vo, no, go, tt = make_object_cloud(n, n_points=O, seed=1)
+    mk, mc, oc = make_grasp_targets(n * k, np.repeat(vo, k, axis=0), seed=7)
+    samples = dict(verts_object=vo, normal_object=no, global_orient_object=go, transf_transl=tt, markers_gen=mk,
+                   object_contact_gen=oc, markers_contact_gen=mc)
+    op = FittingOP({'batch_size': n * k, 'device': 'cuda', 'body_model_path': body_model_dir, 'vposer': VPoserDecoder(seed=0),
+                    'genders': ('male',), 'num_iter': [2, 2, 2], 'verbose': False})
+    out = pose_opt(op, samples, k, 'camera', 'male', save_dir=str(tmp_path))
+    back = np.load(tmp_path / 'fitting_results.npz', allow_pickle=True)
+    assert back['markers_fit'].shape == (n * k, 143, 3) and np.isfinite(back['markers_fit']).all()
+    assert back['body'][()]['body_pose'].shape == (n * k, 63)
+    assert np.array_equal(back['object'][()]['verts_object'][k], vo[1])          # candidate k belongs to object pose 1
+    assert np.array_equal(out['markers'], mk)

@@ -165,3 +165,26 @@ def test_vposer_decoder_shapes_and_unit_rotations():
     aa = vposer_ref.vposer_decode(w, torch.randn(4, 32, generator=g))
     assert aa.shape == (4, 1, 21, 3)
     assert torch.isfinite(aa).all() and (aa.norm(dim=-1) <= np.pi + 1e-4).all()
+
+
+def test_fitting_results_schema_matches_reference_driver(tmp_path):
+    """saga_amd.opt_grasppose.fitting_results_dict writes the keys / nesting / shapes of opt_grasppose.py:194-243
+    (what visualization/vis_pose.py:31-42 reads back)."""
+    from saga_amd.opt_grasppose import BODY_KEYS, fitting_results_dict
+    n, O = 5, 64
+    rng = np.random.default_rng(0)
+    dims = {'betas': 10, 'transl': 3, 'global_orient': 3, 'body_pose': 63, 'leye_pose': 3, 'reye_pose': 3,
+            'left_hand_pose': 24, 'right_hand_pose': 24}
+    params = {k: torch.from_numpy(rng.normal(size=(n, d)).astype(np.float32)) for k, d in dims.items()}
+    out = fitting_results_dict(rng.normal(size=(n, 143, 3)), rng.normal(size=(n, 143, 3)), params, 'male',
+                               rng.random((n, O)), rng.random((n, 143)), 'camera', rng.normal(size=(n, O, 3)),
+                               rng.normal(size=(n, 3)), rng.normal(size=(n, 3)))
+    np.savez(tmp_path / 'fitting_results.npz', **out)
+    back = np.load(tmp_path / 'fitting_results.npz', allow_pickle=True)      # our own file
+    assert set(back.files) == {'markers', 'markers_fit', 'body', 'object', 'contact', 'gender', 'object_name'}
+    body = back['body'][()]
+    assert list(body.keys()) == BODY_KEYS and all(body[k].shape == (n, dims[k]) for k in BODY_KEYS)
+    assert back['markers'].shape == (n, 143, 3) and back['markers_fit'].shape == (n, 143, 3)
+    assert back['object'][()]['verts_object'].shape == (n, O, 3)
+    assert back['contact'][()]['body'].shape == (n, 143) and back['contact'][()]['object'].shape == (n, O)
+    assert list(back['gender']) == ['male'] * n and list(back['object_name']) == ['camera'] * n
