@@ -6,6 +6,7 @@
 // winning chunk give exactly the (best, index) of a sequential strict-'<' scan in index order (lowest index wins
 // ties).  Squared distance = fma(dz,dz, fma(dy,dy, dx*dx)), bit-exact against oracle/csrc/nn_ref.c.  FP32 VALU bound.
 #include <math.h>
+#include <stdlib.h>
 
 #include "saga_common.h"
 #include "nn_scan.h"
@@ -54,11 +55,13 @@ __global__ __launch_bounds__(NTH) void nn_scan_kernel(const float* __restrict__ 
     }
 }
 
-// Database clouds that fit one LDS tile (every call SAGA makes: 2,048 object points / 778 hand vertices) take the
-// two-level scan of nn_fast.h: approximate expanded-form pass (3 fmas per pair) + exact re-evaluation of the candidate
-// chunks.  Same outputs as nn_scan_kernel, bit for bit.
+// Two-level scan of nn_fast.h, tile by tile: approximate expanded-form pass (3 fmas per pair) + exact re-evaluation of
+// the candidate chunks of every tile that can still hold the minimum (each tile has its own centred frame; the exact
+// minimum and its index are carried across tiles with a strict '<', tiles in index order).  Same outputs as
+// nn_scan_kernel, bit for bit.  One tile for every call SAGA makes (2,048 object points / 778 hand vertices); dense
+// clouds (BASELINE config 5: 100,000 points) stream through LDS 2,048 points at a time.
 template <int NQ, int NTH>
-__global__ __launch_bounds__(NTH) void nn_fast_kernel(const float* __restrict__ q, const float* __restrict__ db,
+__global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 1) void nn_fast_kernel(const float* __restrict__ q, const float* __restrict__ db,
                                                       float* __restrict__ dist, int32_t* __restrict__ idx, int Pq, int Pd) {
     __shared__ __attribute__((aligned(16))) float sdb[NNF_TILE_FLOATS(NN_TILE)];
     __shared__ float sred[6 * (NTH / 64)];
@@ -67,20 +70,26 @@ __global__ __launch_bounds__(NTH) void nn_fast_kernel(const float* __restrict__ 
     const int q0 = blockIdx.x * (NTH * NQ);
     const float* qn = q + (size_t)n * Pq * 3;
     const float* dn = db + (size_t)n * Pd * 3;
-    const NnfFrame f = nnf_frame(dn, Pd, sred, tid, NTH);
-    const int cnt_pad = nnf_stage_tile(sdb, dn, Pd, f, tid, NTH);
-    float ox[NQ], oy[NQ], oz[NQ], qx[NQ], qy[NQ], qz[NQ];
+    float ox[NQ], oy[NQ], oz[NQ], best[NQ];
+    int bi[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const int p = min(q0 + tid + i * NTH, Pq - 1);
         ox[i] = qn[p * 3]; oy[i] = qn[p * 3 + 1]; oz[i] = qn[p * 3 + 2];
-        qx[i] = ox[i] - f.cx; qy[i] = oy[i] - f.cy; qz[i] = oz[i] - f.cz;
+        best[i] = INFINITY; bi[i] = 0;
     }
-    __syncthreads();
-    float m1[NQ], m2[NQ], m3[NQ], best[NQ];
-    int c1[NQ], c2[NQ], bi[NQ];
-    nnf_scan<NQ>(sdb, cnt_pad / NNF_CH, qx, qy, qz, m1, m2, m3, c1, c2);
-    nnf_resolve<NQ>(sdb, cnt_pad / NNF_CH, f, 0, qx, qy, qz, ox, oy, oz, m1, m2, m3, c1, c2, best, bi);
+    for (int t0 = 0; t0 < Pd; t0 += NN_TILE) {
+        const int cnt = min(NN_TILE, Pd - t0);
+        const NnfFrame f = nnf_frame(dn + (size_t)t0 * 3, cnt, sred, tid, NTH);      // (barriers: the previous tile is done)
+        const int cnt_pad = nnf_stage_tile(sdb, dn + (size_t)t0 * 3, cnt, f, tid, NTH);
+        float qx[NQ], qy[NQ], qz[NQ], m1[NQ], m2[NQ], m3[NQ];
+        int c1[NQ], c2[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) { qx[i] = ox[i] - f.cx; qy[i] = oy[i] - f.cy; qz[i] = oz[i] - f.cz; }
+        __syncthreads();
+        nnf_scan<NQ>(sdb, cnt_pad / NNF_CH, qx, qy, qz, m1, m2, m3, c1, c2);
+        nnf_resolve<NQ>(sdb, cnt_pad / NNF_CH, f, t0, qx, qy, qz, ox, oy, oz, m1, m2, m3, c1, c2, best, bi);
+    }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const int p = q0 + tid + i * NTH;
@@ -93,18 +102,20 @@ __global__ __launch_bounds__(NTH) void nn_fast_kernel(const float* __restrict__ 
 
 static int launch_scan(const float* q, const float* db, float* dist, int32_t* idx, int N, int Pq, int Pd, hipStream_t st) {
     if (!dist && !idx) return 0;
-    if (Pd <= NN_TILE) {
+    // SAGA_NN_EXACT_SCAN=1 forces the plain 6-op exact scan (cross-checks of the two code paths)
+    const char* force = getenv("SAGA_NN_EXACT_SCAN");
+    if (!(force && force[0] == '1')) {
         if (Pq <= 128) {
             nn_fast_kernel<2, 64><<<dim3(1, N), 64, 0, st>>>(q, db, dist, idx, Pq, Pd);
         } else if (Pq <= 256) {
             nn_fast_kernel<2, 128><<<dim3(1, N), 128, 0, st>>>(q, db, dist, idx, Pq, Pd);
         } else if (Pq <= 512) {
             nn_fast_kernel<2, 256><<<dim3(1, N), 256, 0, st>>>(q, db, dist, idx, Pq, Pd);
-        } else if (Pq <= 1024) {
-            nn_fast_kernel<4, 256><<<dim3(1, N), 256, 0, st>>>(q, db, dist, idx, Pq, Pd);
         } else {
-            dim3 grid((Pq + 256 * 8 - 1) / (256 * 8), N);
-            nn_fast_kernel<8, 256><<<grid, 256, 0, st>>>(q, db, dist, idx, Pq, Pd);
+            // 4 queries per lane (8 would need > 128 VGPRs: the scan wants 3-4 waves per SIMD more than it wants
+            // fewer broadcast LDS reads); clouds of more than 1,024 queries take several blocks per batch element
+            dim3 grid((Pq + 256 * 4 - 1) / (256 * 4), N);
+            nn_fast_kernel<4, 256><<<grid, 256, 0, st>>>(q, db, dist, idx, Pq, Pd);
         }
         SAGA_LAUNCH_CHECK();
         return 0;

@@ -289,6 +289,8 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
         for (int i = 0; i < GL_NQ; ++i) { cx[i] = qx[i] - fo.cx; cy[i] = qy[i] - fo.cy; cz[i] = qz[i] - fo.cz; }
         nnf_scan<GL_NQ>(sObj, Opad / NNF_CH, cx, cy, cz, m1, m2, m3, c1, c2);
         GL_T(2);
+#pragma unroll
+        for (int i = 0; i < GL_NQ; ++i) { best[i] = INFINITY; bi[i] = 0; }
         nnf_resolve<GL_NQ>(sObj, Opad / NNF_CH, fo, 0, cx, cy, cz, qx, qy, qz, m1, m2, m3, c1, c2, best, bi);
         GL_T(3);
 #pragma unroll
@@ -352,6 +354,8 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
             cx[i] = ox[i] - fh.cx; cy[i] = oy[i] - fh.cy; cz[i] = oz[i] - fh.cz;
         }
         nnf_scan<GLF_NO>(sHand, Hpad / NNF_CH, cx, cy, cz, m1, m2, m3, c1, c2);
+#pragma unroll
+        for (int i = 0; i < GLF_NO; ++i) { best[i] = INFINITY; bj[i] = 0; }
         nnf_resolve<GLF_NO>(sHand, Hpad / NNF_CH, fh, 0, cx, cy, cz, ox, oy, oz, m1, m2, m3, c1, c2, best, bj);
 #pragma unroll
         for (int i = 0; i < GLF_NO; ++i) {

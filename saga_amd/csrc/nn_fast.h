@@ -207,8 +207,9 @@ __device__ __forceinline__ void nnf_exact_chunk(const float* __restrict__ s, con
     }
 }
 
-// Exact pass.  qc*: framed queries (for the margin), o*: original query coordinates.  best/bi: exact squared distance
-// and index (global index of point 0 of the tile = base) of the sequential exact scan.
+// Exact pass.  qc*: framed queries (for the margin), o*: original query coordinates.  best/bi (IN/OUT; the caller
+// starts them at +INF / 0): exact squared distance and index of the sequential exact scan over every tile so far
+// (global index of point 0 of this tile = base; tiles must come in index order).
 template <int NQ>
 __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_chunks, const NnfFrame& f, int base,
                                             const float (&qx)[NQ], const float (&qy)[NQ], const float (&qz)[NQ],
@@ -221,7 +222,9 @@ __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_c
         const float qq = __builtin_fmaf(qz[i], qz[i], __builtin_fmaf(qy[i], qy[i], qx[i] * qx[i])) * 1.001f;
         const float E = 5.9604645e-7f * f.rp * (f.rp + sqrtf(qq));                       // 10 u Rp (Rp + Rq)
         const float thr = m1[i] + (2.f * E + 1.0e-6f * (fmaxf(m1[i] + qq, 0.f) + E));
-        best[i] = INFINITY; bi[i] = 0;
+        // a tile whose best possible distance cannot beat the exact minimum carried in from earlier tiles is skipped:
+        // D(p) >= t(p) - E + |q - c|^2 (1 - 3u) for every point of this tile, and its fp32 distance is >= D (1 - 6u)
+        if (m1[i] - E + qq * 0.998f > best[i] * 1.000001f) continue;
         if (m3[i] > thr) {
             // the exact winner is in chunk c1 or c2: lower chunk first so that ties keep the lowest index
             // (c2 only matters when its minimum is inside the margin)

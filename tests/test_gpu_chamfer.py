@@ -85,6 +85,20 @@ def test_chamfer_two_level_scan_adversarial(case):
     _check(x.float().contiguous(), y.float().contiguous())
 
 
+@pytest.mark.parametrize('N,P1,P2', [(2, 700, 5000), (1, 3000, 20001), (1, 64, 100000)])
+def test_chamfer_dense_clouds_multi_tile(N, P1, P2):
+    """Databases larger than one LDS tile (BASELINE config 5 streams 100,000 points): the exact minimum is carried
+    across tiles; near-ties across tile boundaries included (points on a sphere around some of the queries)."""
+    g = torch.Generator().manual_seed(P2)
+    y = torch.randn(N, P2, 3, generator=g) * 0.2 + torch.tensor([0.4, -0.2, 1.0])
+    x = torch.randn(N, P1, 3, generator=g) * 0.25 + torch.tensor([0.4, -0.2, 1.0])
+    c = x[:, :8].mean(dim=1, keepdim=True)
+    y[:, ::7] = c + _sphere(y[:, ::7].shape[1], g)[None] * 0.3      # every 7th point equidistant from a query-side centre
+    x[:, 0] = c[:, 0]
+    y[:, P2 - 1] = y[:, 3]                                            # duplicate in the last tile: lowest index must win
+    _check(x.contiguous(), y.contiguous())
+
+
 def test_chamfer_both_call_forms_and_errors():
     import saga_amd.chamfer_distance as chd
     x = torch.randn(1, 5, 3).cuda()

@@ -69,11 +69,18 @@ def test_fused_loss_neighbours_equal_exact_chamfer_at_full_batch(body_model_dir)
     assert torch.equal(op.workspace_view('idx_o2h', O, (B_FULL, O), torch.int32), i2)
     _, _, im, _ = chd.ChamferDistance(markers, obj)
     assert torch.equal(op.workspace_view('idx_m2o', O, (B_FULL, M), torch.int32), im)
-    # and against the multi-tile exact 6-op scan (databases > 2048 points take that kernel): pad the object cloud with
-    # far-away points so the same neighbours must come out of the other code path
+    # and through the other code paths: a second LDS tile (pad the object cloud with far-away points), and the plain
+    # 6-op exact scan
     far = torch.full((B_FULL, 64, 3), 1.0e3, device='cuda')
-    _, _, i1x, _ = chd.ChamferDistance(hand, torch.cat([obj, far], 1))
+    _, _, i1x, _ = chd.ChamferDistance(hand, torch.cat([obj, far], 1))          # two tiles, minimum carried across
     assert torch.equal(i1x, i1)
+    import os
+    os.environ['SAGA_NN_EXACT_SCAN'] = '1'                                       # the plain 6-op exact scan kernel
+    try:
+        d1e, d2e, i1e, i2e = chd.ChamferDistance(hand, obj)
+    finally:
+        del os.environ['SAGA_NN_EXACT_SCAN']
+    assert torch.equal(i1e, i1) and torch.equal(i2e, i2) and torch.equal(d1e, d1) and torch.equal(d2e, d2)
     # distances are the exact fp32 chain of the winner
     g = obj.gather(1, i1.long()[..., None].expand(-1, -1, 3))
     dx, dy, dz = (hand - g).unbind(-1)
