@@ -39,7 +39,7 @@ def load_grasp_indices(path=None):
     the reference's own expressions (``tests/golden/make_golden.py``), including the CPython-``set``
     ordering that selects the 172 foot vertices."""
     d = np.load(path or _DATA, allow_pickle=False)
-    return {k: d[k] for k in ('markers_143', 'rhand', 'lhand', 'foot', 'rhand_weight')}
+    return {k: d[k] for k in ('markers_143', 'rhand', 'lhand', 'foot', 'rhand_weight', 'foot_sizes')}
 
 
 class FittingOP:
