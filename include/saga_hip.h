@@ -294,9 +294,11 @@ int saga_fit_best_update(const float* loss, const float* vars, const float* mark
 /* ------------------------------------------------------------------------------------------
  * Per-kernel timing for bench.py (no counterpart in the reference, whose only timing hook is the
  * disabled `time per sample` log at WholeGraspPose/models/fittingop.py:376,491-492).
- * When enabled, every kernel launch of the entry points above is bracketed by a hipEvent pair on
+ * saga_profile_enable(1): every kernel launch of the entry points above is bracketed by a hipEvent pair on
  * the launch stream; saga_profile_read() synchronises them and returns, per kernel id, the summed
- * elapsed milliseconds and the number of launches since the last read.  Not thread-safe.
+ * elapsed milliseconds and the number of launches since the last read.  saga_profile_enable(2) brackets only the
+ * blend-contraction GEMM launches (the roofline kernel: two event pairs per iteration instead of seventeen, which
+ * cost ~0.08 ms of a 5 ms iteration); 0 switches it off.  Not thread-safe.
  * ------------------------------------------------------------------------------------------ */
 #define SAGA_PROF_POSE_FWD   0
 #define SAGA_PROF_BLEND_FWD  1   /* FP32-MFMA blend contraction, forward  */

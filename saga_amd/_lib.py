@@ -164,7 +164,8 @@ def require_device(*tensors):
 
 
 def profile_enable(on=True):
-    check(load().saga_profile_enable(1 if on else 0), 'saga_profile_enable')
+    """True / 1: bracket every kernel; 2: only the blend GEMM launches; False / 0: off."""
+    check(load().saga_profile_enable(int(on)), 'saga_profile_enable')
 
 
 def profile_read():

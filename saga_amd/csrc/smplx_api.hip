@@ -22,13 +22,14 @@ int saga_launch_skin_bwd(const saga_model* m, const float* A, const float* g_ver
 // the stream it is launched on; saga_profile_read() resolves the pairs.  Off by default (zero overhead).
 #include <vector>
 struct ProfPair { hipEvent_t a, b; int id; };
-static bool g_prof_on = false;
+static int g_prof_on = 0;       // 0 off, 1 every kernel, 2 only the blend GEMM launches (the roofline kernel)
 static std::vector<ProfPair> g_prof_pairs;
 static std::vector<ProfPair> g_prof_pool;
 
 struct ProfScope {
     hipStream_t st; hipEvent_t b = nullptr; bool on;
-    ProfScope(int id, hipStream_t s) : st(s), on(g_prof_on) {
+    ProfScope(int id, hipStream_t s)
+        : st(s), on(g_prof_on == 1 || (g_prof_on == 2 && (id == SAGA_PROF_BLEND_FWD || id == SAGA_PROF_BLEND_BWD))) {
         if (!on) return;
         ProfPair p;
         if (!g_prof_pool.empty()) { p = g_prof_pool.back(); g_prof_pool.pop_back(); }
@@ -41,12 +42,12 @@ struct ProfScope {
     ~ProfScope() { if (on) (void)hipEventRecord(b, st); }
 };
 
-int saga_prof_is_on() { return g_prof_on; }
+int saga_prof_is_on() { return g_prof_on != 0; }
 void* saga_prof_begin(int id, void* stream) { return g_prof_on ? new ProfScope(id, (hipStream_t)stream) : nullptr; }
 void saga_prof_end(void* scope) { delete (ProfScope*)scope; }
 
 extern "C" int saga_profile_enable(int on) {
-    g_prof_on = on != 0;
+    g_prof_on = on < 0 ? 0 : (on > 2 ? 1 : on);
     return 0;
 }
 
