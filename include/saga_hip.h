@@ -272,7 +272,10 @@ long long saga_fit_workspace_offset(const saga_model_t* m, const saga_grasp_tabl
 
 /*   vars   [B,SAGA_VAR_STRIDE]  in/out   optimiser variables
  *   adam_m, adam_v [B,SAGA_VAR_STRIDE]  in/out  exp_avg / exp_avg_sq of the stage's optimiser
- *   ws     workspace (contents undefined on entry; holds every intermediate of the iteration afterwards)
+ *   ws     workspace: ZERO-INITIALISED by the caller before its first use and not written by the caller afterwards
+ *          (it holds every intermediate of the iteration, and the dense vertex-gradient rows are zero-filled only once:
+ *          later iterations rewrite the same vertices -- a workspace that was not zeroed is still handled, its rows are
+ *          filled on first use unless a stale word happens to equal the 32-bit tag)
  *   loss   [B]       out  per-candidate total loss (before the update)
  *   loss_terms [B,16] out or NULL: total, rec, body_rec, marker contact, object contact, prior contact, hand collision,
  *              object collision, foot, reg (loss_dict :225-236), then the four counts of :238-242, 2 pads

@@ -18,6 +18,11 @@
 
 void* saga_prof_begin(int id, void* stream);
 void saga_prof_end(void* scope);
+int saga_grasp_loss_bwd_tagged(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* g_terms, const float* verts,
+                               const float* obj, const float* markers_target, const float* c_markers, const float* c_object,
+                               const float* markers_rec, const float* hand_rec, const float* h2o_signed,
+                               const float* o2h_signed, const int32_t* idx_m2o, const int32_t* idx_h2o,
+                               const int32_t* idx_o2h, float* g_verts, int B, int O, int32_t* zero_tag, int32_t tag, void* stream);
 int saga_launch_gemm_nt(int epi, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, const float* bias,
                         const float* aux, int M, int N, int K, hipStream_t st);
 
@@ -101,6 +106,7 @@ struct FitWs {
     int32_t *idx_m2o, *idx_h2o, *idx_o2h;
     float *g_verts, *gvp, *slab, *dA, *g_shape, *g_pose, *g_transl;       // SMPL-X backward
     float *g_x6, *g_h, *g_z, *grad;                                       // reverse parameter maps
+    int32_t* zero_tag;                                                    // [B] rows of g_verts already zero outside the touched vertices
     size_t total;
 };
 
@@ -125,6 +131,7 @@ static FitWs fit_ws_carve(float* base, const saga_model* m, const saga_grasp_tab
     w.g_verts = take(b * V * 3); w.gvp = take(b * Npad); w.slab = take((size_t)SAGA_BWD_SPLITK * b * FEAT_K);
     w.dA = take(b * SAGA_DA_STRIDE); w.g_shape = take(b * (S > 0 ? S : 1)); w.g_pose = take(b * 165); w.g_transl = take(b * 3);
     w.g_x6 = take(b * X6_LD); w.g_h = take(b * hidden); w.g_z = take(b * 128); w.grad = take(b * VS);
+    w.zero_tag = (int32_t*)take(b);
     w.total = off;
     return w;
 }
@@ -421,10 +428,19 @@ extern "C" int saga_fit_step(const saga_model_t* m, const saga_decoder_t* d, con
         loss_sum_kernel<<<(B + 127) / 128, 128, 0, st>>>(w.terms, vars, lc, w.g_terms, loss, loss_terms, B);
         SAGA_LAUNCH_CHECK();
     }
-    if ((rc = saga_grasp_loss_bwd(m, tb, w.g_terms, w.verts, prob->obj, prob->markers_target, prob->c_markers, prob->c_object,
-                                  markers_rec, w.hand_rec, w.h2o_signed, w.o2h_signed, w.idx_m2o, w.idx_h2o, w.idx_o2h, w.g_verts,
-                                  B, O, stream)))
-        return rc;
+    {
+        // the dense gradient rows of the workspace are zero-filled once: every call rewrites the same (tables') vertices.
+        // The tag ties the "already zero" mark to this table set, mesh and workspace address; it is never 0, so a
+        // zero-initialised workspace (the contract) always fills on first use.
+        uint64_t h = (uint64_t)(uintptr_t)tb->unique_ids * 0x9E3779B97F4A7C15ull ^ (uint64_t)(uintptr_t)w.g_verts * 0xC2B2AE3D27D4EB4Full ^
+                     ((uint64_t)tb->n_unique << 32) ^ (uint64_t)m->V;
+        int32_t tag = (int32_t)(h ^ (h >> 32));
+        if (tag == 0) tag = 1;
+        if ((rc = saga_grasp_loss_bwd_tagged(m, tb, w.g_terms, w.verts, prob->obj, prob->markers_target, prob->c_markers,
+                                             prob->c_object, markers_rec, w.hand_rec, w.h2o_signed, w.o2h_signed, w.idx_m2o,
+                                             w.idx_h2o, w.idx_o2h, w.g_verts, B, O, w.zero_tag, tag, stream)))
+            return rc;
+    }
     if ((rc = saga_smplx_bwd(m, w.g_verts, nullptr, w.full_pose, w.rot, w.jrest, w.chain, w.A, w.v_posed, w.g_shape, w.g_pose,
                              w.g_transl, w.gvp, w.slab, w.dA, nullptr, B, stream)))
         return rc;

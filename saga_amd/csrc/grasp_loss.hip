@@ -428,7 +428,8 @@ __global__ __launch_bounds__(GL_BWD_THREADS) void grasp_loss_bwd_kernel(
     const float* __restrict__ obj, const float* __restrict__ mk_target, const float* __restrict__ c_mk,
     const float* __restrict__ c_obj, const float* __restrict__ markers_rec, const float* __restrict__ hand_rec,
     const float* __restrict__ h2o_signed, const float* __restrict__ o2h_signed, const int32_t* __restrict__ idx_m2o,
-    const int32_t* __restrict__ idx_h2o, const int32_t* __restrict__ idx_o2h, float* __restrict__ g_verts, int V, int O) {
+    const int32_t* __restrict__ idx_h2o, const int32_t* __restrict__ idx_o2h, float* __restrict__ g_verts, int V, int O,
+    int32_t* __restrict__ zero_tag, int32_t tag) {
     // Accumulators are 64-bit fixed point (2^-40 units, range +-2^23): integer adds are associative, so the scatter-add of
     // many object points into one hand vertex gives the same bits whatever order the LDS atomics land in, and the sum is
     // the exactly rounded one (float atomics would make the whole iteration run-to-run irreproducible).
@@ -444,8 +445,11 @@ __global__ __launch_bounds__(GL_BWD_THREADS) void grasp_loss_bwd_kernel(
     const float* vb = verts + (size_t)b * V * 3;
     const float* ob = obj + (size_t)b * O * 3;
     for (int i = tid; i < U * 3; i += GL_BWD_THREADS) acc[i] = 0ull;
-    {   // zero-fill this candidate's row of the dense gradient (no separate memset pass): scalar head up to 16-B
-        // alignment, float4 body, scalar tail; the scatter below comes after a barrier
+    // Zero-fill this candidate's row of the dense gradient (no separate memset pass): scalar head up to 16-B alignment,
+    // float4 body, scalar tail; the scatter below comes after a barrier.  With a tag array (saga_fit_step's workspace,
+    // which nobody else writes) the fill happens only the first time: every later call rewrites exactly the same
+    // vertices (the tables' unique ids) and everything else is still zero.
+    if (!zero_tag || zero_tag[b] != tag) {
         float* gb0 = g_verts + (size_t)b * V * 3;
         const int n = V * 3;
         const int head = min(n, (int)((16 - ((uintptr_t)gb0 & 15)) & 15) >> 2);
@@ -507,6 +511,7 @@ __global__ __launch_bounds__(GL_BWD_THREADS) void grasp_loss_bwd_kernel(
     __syncthreads();
     float* gb = g_verts + (size_t)b * V * 3;
     for (int i = tid; i < U * 3; i += GL_BWD_THREADS) gb[tb.unique_ids[i / 3] * 3 + (i % 3)] = (float)((double)(long long)acc[i] * 9.094947017729282e-13);
+    if (zero_tag && tid == 0) zero_tag[b] = tag;
 }
 
 static int check_tables(const saga_grasp_tables_t* tb) {
@@ -552,11 +557,27 @@ extern "C" int saga_grasp_loss_fwd(const saga_model_t* m, const saga_grasp_table
     return 0;
 }
 
+// zero_tag (device int32 [B], may be NULL) / tag: see the kernel; used by saga_fit_step only
+int saga_grasp_loss_bwd_tagged(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* g_terms, const float* verts,
+                               const float* obj, const float* markers_target, const float* c_markers, const float* c_object,
+                               const float* markers_rec, const float* hand_rec, const float* h2o_signed,
+                               const float* o2h_signed, const int32_t* idx_m2o, const int32_t* idx_h2o,
+                               const int32_t* idx_o2h, float* g_verts, int B, int O, int32_t* zero_tag, int32_t tag, void* stream);
+
 extern "C" int saga_grasp_loss_bwd(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* g_terms, const float* verts,
                                    const float* obj, const float* markers_target, const float* c_markers, const float* c_object,
                                    const float* markers_rec, const float* hand_rec, const float* h2o_signed,
                                    const float* o2h_signed, const int32_t* idx_m2o, const int32_t* idx_h2o,
                                    const int32_t* idx_o2h, float* g_verts, int B, int O, void* stream) {
+    return saga_grasp_loss_bwd_tagged(m, tb, g_terms, verts, obj, markers_target, c_markers, c_object, markers_rec, hand_rec, h2o_signed,
+                                      o2h_signed, idx_m2o, idx_h2o, idx_o2h, g_verts, B, O, nullptr, 0, stream);
+}
+
+int saga_grasp_loss_bwd_tagged(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* g_terms, const float* verts,
+                               const float* obj, const float* markers_target, const float* c_markers, const float* c_object,
+                               const float* markers_rec, const float* hand_rec, const float* h2o_signed,
+                               const float* o2h_signed, const int32_t* idx_m2o, const int32_t* idx_h2o,
+                               const int32_t* idx_o2h, float* g_verts, int B, int O, int32_t* zero_tag, int32_t tag, void* stream) {
     SAGA_CHECK_ARG(m, "saga_grasp_loss_bwd: null model");
     int rc = check_tables(tb);
     if (rc) return rc;
@@ -569,7 +590,8 @@ extern "C" int saga_grasp_loss_bwd(const saga_model_t* m, const saga_grasp_table
     void* prof = saga_prof_begin(SAGA_PROF_GRASP_BWD, stream);
     hipError_t e = hipSuccess;
     grasp_loss_bwd_kernel<<<B, GL_BWD_THREADS, 0, st>>>(*tb, g_terms, verts, obj, markers_target, c_markers, c_object, markers_rec,
-                                                        hand_rec, h2o_signed, o2h_signed, idx_m2o, idx_h2o, idx_o2h, g_verts, m->V, O);
+                                                        hand_rec, h2o_signed, o2h_signed, idx_m2o, idx_h2o, idx_o2h, g_verts, m->V, O,
+                                                        zero_tag, tag);
     saga_prof_end(prof);
     SAGA_HIP(e);
     SAGA_LAUNCH_CHECK();

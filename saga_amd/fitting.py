@@ -301,7 +301,7 @@ class FittingOP:
     def _workspace(self, n_obj):
         n = _lib.load().saga_fit_workspace_floats(self.bm.handle(self.device), ctypes.byref(self.tables.struct), self.batch_size, n_obj)
         if self._ws is None or self._ws.numel() < n:
-            self._ws = torch.empty(n, device=self.device, dtype=torch.float32)
+            self._ws = torch.zeros(n, device=self.device, dtype=torch.float32)      # contract: zero-initialised
         return self._ws
 
     def make_problem(self, body_markers, verts_object, normal_object, contacts_object, contacts_markers):

@@ -182,3 +182,32 @@ def test_autograd_fitting_trajectory_matches_native(body_model_dir):
     for k in p_a[-1]:
         np.testing.assert_allclose(p_n[-1][k].cpu().numpy(), p_a[-1][k].reshape(B, -1).cpu().numpy(), atol=2e-3, err_msg=k)
     np.testing.assert_allclose(mf_n[-1], mf_a[-1], atol=2e-3)
+
+
+def test_workspace_reuse_across_problems_is_clean(body_model_dir):
+    """saga_fit_step zero-fills the dense vertex-gradient rows of its workspace only once (later calls rewrite the same
+    vertices).  A second, different problem on the same workspace must give exactly what a fresh workspace gives."""
+    B = 4
+    op_a, vp, idx, var_np, d = _setup(body_model_dir, B)
+    op_b, *_ = _setup(body_model_dir, B)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for op in (op_a, op_b):
+        op.bm = op.bm_male
+    prob1 = op_a.make_problem(cu(d['markers']), cu(d['verts_o']), cu(d['normals_o']), cu(d['oc']), cu(d['mc']))
+    op_a.set_variables(var_np)
+    for _ in range(3):
+        op_a.native_step(2, prob1)
+    # second problem: other candidates, shifted objects
+    var2 = make_candidate_params(B, seed=99, scale=0.3)
+    vo2 = d['verts_o'][::-1] + np.float32(0.01)
+    args2 = (cu(d['markers'][::-1]), cu(vo2), cu(d['normals_o'][::-1]), cu(d['oc'][::-1]), cu(d['mc'][::-1]))
+    op_a.reset()
+    op_a.set_variables(var2)
+    op_b.set_variables(var2)
+    pa, pb = op_a.make_problem(*args2), op_b.make_problem(*args2)
+    for _ in range(2):
+        la, ma = op_a.native_step(2, pa)
+        lb, mb = op_b.native_step(2, pb)
+    assert torch.equal(la, lb) and torch.equal(ma, mb) and torch.equal(op_a.vars, op_b.vars)
+    assert torch.equal(op_a.workspace_view('g_vertices', 2048, (B, op_a.bm.num_verts, 3)),
+                       op_b.workspace_view('g_vertices', 2048, (B, op_b.bm.num_verts, 3)))
