@@ -147,10 +147,10 @@ extern "C" int saga_model_create(saga_model_t** out, const saga_model_desc_t* d)
             int k = 0;
             for (int j = 0; j < NJ; ++j) {
                 float w = d->lbs_weights_host[(size_t)v * NJ + j];
-                Wd[(size_t)v * WT_COLS + j] = w;
+                Wd[(size_t)v * WT_COLS + (j & 15) * 4 + (j >> 4)] = w;      // column j at slot (j%16)*4 + j/16
                 if (w != 0.f) { wi[(size_t)v * KW + k] = j; wv[(size_t)v * KW + k] = w; ++k; }
             }
-            Wd[(size_t)v * WT_COLS + NJ] = 1.f;
+            Wd[(size_t)v * WT_COLS + (NJ & 15) * 4 + (NJ >> 4)] = 1.f;
         }
         if ((rc = upload(&m->w_idx, wi)) || (rc = upload(&m->w_val, wv)) || (rc = upload(&m->Wd, Wd))) goto fail;
     }

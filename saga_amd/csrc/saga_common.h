@@ -65,7 +65,8 @@ struct saga_model {
     // skinning weights: compressed rows (joint, weight) and dense padded table for the dA reduction
     int32_t* w_idx;     // [V, KW]
     float*   w_val;     // [V, KW] (pad entries: idx 0, weight 0)
-    float*   Wd;        // [Vpad4, 64]  Wd[v][j] = W[v][j] (j<55), 1 (j=55), 0 (j>55); rows >= V are 0
+    float*   Wd;        // [Vpad4, 64]  column j of W (j<55; j=55: all ones; j>55: 0) sits at slot (j%16)*4 + j/16, so the
+                        // four N-tile values of an MFMA lane (joints i16, i16+16, i16+32, i16+48) are one 16-B load; rows >= V are 0
     int Vpad4;          // roundup(V, 256)
     // faces / landmarks / extra joints
     int32_t* faces;     // [F,3]

@@ -237,6 +237,18 @@ __global__ __launch_bounds__(SKIN_THREADS) void skin_bwd_vposed_kernel(const flo
 // GEMM view: rows = (candidate, rc) pairs, 4 candidates x 12 = 48 = three 16-row MFMA tiles; columns = 64 padded
 // joints (column 55 of Wd is all ones -> sum_v g = d transl); contraction over vertices, 4 per v_mfma_f32_16x16x4_f32.
 // Block = 4 waves, each wave reduces a quarter of the vertex range; partials are combined through LDS in wave order.
+#ifdef DA_PHASE_TIMING
+__device__ unsigned long long da_phase[8];
+extern "C" int saga_debug_read_da_phases(unsigned long long* out) {
+    unsigned long long z[8] = {0};
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(da_phase), sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(da_phase), z, sizeof(z));
+    return (int)e;
+}
+#define DA_T(i) do { const unsigned long long t_ = clock64(); tacc[i] += t_ - t_prev; t_prev = t_; } while (0)
+#else
+#define DA_T(i)
+#endif
 #define DA_CANDS 4
 #define DA_STEP 16      // vertices per wave per iteration: 4 k-steps of v_mfma_f32_16x16x4_f32
 #define DA_XSTRIDE (DA_STEP * 8 + 16)  // floats per candidate plane of a staging tile: = 16 mod 32, so the A-operand reads of the two
@@ -313,14 +325,34 @@ __global__ __launch_bounds__(256) void skin_bwd_dA_kernel(const float* __restric
     }
     float* gvp_base = FUSE ? g_vposed + (size_t)st_b * Npad : nullptr;
     if (s_begin < s_end) fetch(s_begin);
+#ifdef DA_PHASE_TIMING
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, t_prev = clock64();
+#endif
     for (int step = s_begin; step < s_end; ++step) {
         const int v0 = step * DA_STEP;
+        // B operands of the four k-steps: joints i16 + 16*nt of vertex v0 + 4*ks + kq, one 16-B load per k-step (the table
+        // stores them side by side; rows >= V are zero).  Requested FIRST: what limits this kernel is the vector-memory
+        // issue rate (16 dword loads per step cost 2.4k cycles of issue per wave against 1.5k cycles of MFMA), and the
+        // staging and g_v_posed arithmetic below run while these are in flight.  The rows fetched one step ago are older
+        // in vmcnt order, so consuming them does not wait for these.
+        float bw[4][4];
+        {
+            const float4* wlane = reinterpret_cast<const float4*>(Wd + (size_t)v0 * WT_COLS + kq * WT_COLS) + i16;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float4 w4 = wlane[ks * 4 * (WT_COLS / 4)];
+                bw[ks][0] = w4.x; bw[ks][1] = w4.y; bw[ks][2] = w4.z; bw[ks][3] = w4.w;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        DA_T(0);
         {
             const bool ok = (b0 + st_cd < B) && (v0 + st_v < V);
             const float z = ok ? 1.f : 0.f;
             *reinterpret_cast<float4*>(xw) = make_float4(ok ? rg.x : 0.f, ok ? rg.y : 0.f, ok ? rg.z : 0.f, ok ? rp.x : 0.f);
             *reinterpret_cast<float4*>(xw + 4) = make_float4(ok ? rp.y : 0.f, ok ? rp.z : 0.f, z, 0.f);
         }
+        DA_T(1);
         float3 gvp;
         bool gvp_ok = false;
         if (FUSE) {
@@ -344,17 +376,11 @@ __global__ __launch_bounds__(256) void skin_bwd_dA_kernel(const float* __restric
             gvp.z = T[2] * rg.x + T[5] * rg.y + T[8] * rg.z;
             gvp_ok = (b0 + st_cd < B) && (v0 + st_v < V);
         }
-        // B operands of the four k-steps: Wd[v][16*nt + i16] (rows >= V of the padded table are zero)
-        float bw[4][4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const float* wrow = Wd + (size_t)(v0 + ks * 4 + kq) * WT_COLS + i16;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bw[ks][nt] = wrow[nt * 16];
-        }
+        DA_T(2);
         fetch(min(step + 1, s_end - 1));        // unconditional (a branch here makes hipcc wait for the loads at the join)
         if (FUSE && gvp_ok) *reinterpret_cast<float3*>(gvp_base + (size_t)(v0 + st_v) * 3) = gvp;
         __builtin_amdgcn_wave_barrier();
+        DA_T(3);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int vl = ks * 4 + kq;          // vertex within the step for this lane's k
@@ -367,7 +393,12 @@ __global__ __launch_bounds__(256) void skin_bwd_dA_kernel(const float* __restric
             }
         }
         __builtin_amdgcn_wave_barrier();
+        DA_T(4);
     }
+#ifdef DA_PHASE_TIMING
+    if (lane == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(&da_phase[i], tacc[i]);
+#endif
     // cross-wave reduction, fixed order (w0 + w2) + (w1 + w3), in the accumulators' own register layout
     // (sRed aliases the staging tiles: wait until every wave has left the main loop)
     __syncthreads();
