@@ -33,13 +33,14 @@ PARAM_KEYS = ['transl', 'global_orient', 'betas', 'body_pose', 'left_hand_pose',
 
 
 def load_grasp_indices(path=None):
-    """markers_143 / rhand / foot vertex ids and rhand_weight (``fittingop.py:86-124``).
+    """markers_143 / rhand / foot vertex ids and rhand_weight (``fittingop.py:86-124``), plus the 79 'f0_p5' markers
+    GraspMotion-Opt fits (``opt_graspmotion.py:408``).
 
     The packaged ``data/grasp_indices.npz`` was derived from the reference's ``body_utils`` files with
     the reference's own expressions (``tests/golden/make_golden.py``), including the CPython-``set``
     ordering that selects the 172 foot vertices."""
     d = np.load(path or _DATA, allow_pickle=False)
-    return {k: d[k] for k in ('markers_143', 'rhand', 'lhand', 'foot', 'rhand_weight', 'foot_sizes')}
+    return {k: d[k] for k in ('markers_143', 'markers_f0_p5', 'rhand', 'lhand', 'foot', 'rhand_weight', 'foot_sizes')}
 
 
 class FittingOP:

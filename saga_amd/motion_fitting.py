@@ -1,0 +1,250 @@
+"""GraspMotion-Opt on the HIP operators: the counterpart of ``MotionFill/models/fittingop.py:25-428`` (SURVEY.md
+section 8f, f2), batched over S independent sequences.
+
+The reference optimises ONE sequence per ``FittingOP`` (``opt_graspmotion.py:469-513``): stage 1 fits the 79 markers of
+each of the T = 61 frames in turn (one Adam, whose moments carry over from frame to frame, ``:283-340``); stage 2
+optimises all frames of the sequence at once (``:342-414``) with marker, end-pose, skating, contact, collision,
+hand-angle, hand-smoothness and regulariser terms.  Here S sequences share every launch: frames x sequences are the
+batch of the SMPL-X forward/backward, of the vertex-normal kernel and of the nearest-neighbour search (BASELINE config
+4: S = 256 -> 15,616 bodies per stage-2 iteration).  The objective handed to ``backward`` is the SUM over sequences of
+the reference's per-sequence loss and Adam is element-wise, so each sequence follows exactly the update sequence of
+its own B = 1 run (tests/test_gpu_motion.py checks S = 2 against two oracle runs).
+
+Not part of this path: the learned smoothness prior (``body_smooth_loss`` ``:70-130``, a convolutional auto-encoder
+with a pretrained snapshot).  Pass ``body_smooth_loss=callable(body_verts [S,T,V,3], body_params [S,T,96]) -> [S]`` in
+the config to add it; without one the term is left out, whatever ``stage2_weight_loss_smooth`` says.
+"""
+import numpy as np
+import torch
+import torch.optim as optim
+
+from . import smplx as _smplx
+from . import motion_losses as ml
+from .fitting import load_grasp_indices
+from .rotations import cont6d_to_aa
+from .vposer import VPoserDecoder
+
+
+def angle_axis_to_rotation_matrix(aa, eps=1e-6):
+    """``torchgeometry.angle_axis_to_rotation_matrix`` (upper-left 3x3) as ``ContinousRotReprDecoder.aa2matrot`` uses it
+    (``utils/como/como_utils.py:219-226``): Rodrigues with the axis normalised by (theta + 1e-6), first-order Taylor
+    form where theta^2 <= 1e-6.  torchgeometry is not in the reference tree: restated from its published source."""
+    aa = aa.reshape(-1, 3)
+    theta2 = (aa * aa).sum(-1, keepdim=True)
+    theta = torch.sqrt(theta2)
+    w = aa / (theta + eps)
+    wx, wy, wz = w[:, 0:1], w[:, 1:2], w[:, 2:3]
+    c, s = torch.cos(theta), torch.sin(theta)
+    one = 1.0
+    normal = torch.cat([c + wx * wx * (one - c), wx * wy * (one - c) - wz * s, wy * s + wx * wz * (one - c),
+                        wz * s + wx * wy * (one - c), c + wy * wy * (one - c), -wx * s + wy * wz * (one - c),
+                        -wy * s + wx * wz * (one - c), wx * s + wy * wz * (one - c), c + wz * wz * (one - c)], dim=1)
+    rx, ry, rz = aa[:, 0:1], aa[:, 1:2], aa[:, 2:3]
+    k1 = torch.ones_like(rx)
+    taylor = torch.cat([k1, -rz, ry, rz, k1, -rx, -ry, rx, k1], dim=1)
+    return torch.where(theta2 > eps, normal, taylor).reshape(-1, 3, 3)
+
+
+def convert_to_6D_all(aa):
+    """``como_utils.py:311-314``: axis-angle -> first two columns of R, row-major [N,6]."""
+    return angle_axis_to_rotation_matrix(aa)[:, :, :-1].reshape(-1, 6)
+
+
+def convert_to_3D_rot(x):
+    """``como_utils.py:295-307``: [transl 3 | rot 6D | rest] -> [transl 3 | axis-angle 3 | rest] (fused 6D->aa kernel)."""
+    return torch.cat([x[:, :3], cont6d_to_aa(x[:, 3:9]), x[:, 9:]], dim=-1)
+
+
+def gen_body_mesh_v1(body_params, smplx_model, vposer_model):
+    """``utils/utils_body.py:93-106``: [N, 3+3+10+32+24+24] -> (vertices [N,V,3], SMPL-X keyword dict)."""
+    bs = body_params.shape[0]
+    d = {'transl': body_params[:, 0:3], 'global_orient': body_params[:, 3:6], 'betas': body_params[:, 6:16],
+         'body_pose': vposer_model.decode(body_params[:, 16:48], output_type='aa').view(bs, -1),
+         'left_hand_pose': body_params[:, 48:72], 'right_hand_pose': body_params[:, 72:]}
+    return smplx_model(return_verts=True, **d).vertices, d
+
+
+class FittingOP:
+    """``FittingOP(fittingconfig)`` with the reference's keys (``opt_graspmotion.py:470-495``): T, gender, smplx_beta,
+    init_lr_stage1/2, num_iter, device, markers_ids, markers_ids_143, stage1_weight_loss_*, stage2_weight_loss_*.
+    Additional optional keys: ``n_seq`` (S; ``smplx_beta`` is then [S,10]), ``start_t`` (30), ``body_model_path``,
+    ``vposer``, ``smplx_kwargs``, ``indices`` (foot groups), ``body_smooth_loss`` (see the module docstring)."""
+
+    def __init__(self, fittingconfig):
+        cfg = dict(T=61, gender='male', device='cuda', n_seq=1, start_t=30, init_lr_stage1=0.1, init_lr_stage2=0.01,
+                   num_iter=[100, 300], body_model_path='./body_utils/body_models', vposer=None, smplx_kwargs={},
+                   indices=None, body_smooth_loss=None,
+                   stage1_weight_loss_rec_markers=1.0, stage1_weight_loss_vposer=0.02, stage1_weight_loss_shape=0.01,
+                   stage1_weight_loss_hand=0.01,
+                   stage2_weight_loss_rec_markers=0.1, stage2_weight_loss_end_markers_fit=10, stage2_weight_loss_vposer=0.02,
+                   stage2_weight_loss_hand=0.02, stage2_weight_loss_skating=0.05, stage2_weight_loss_smooth=2e7,
+                   stage2_weight_loss_collision=10, stage2_weight_loss_contact=60, stage2_weight_loss_hand_smooth=1,
+                   stage2_weight_loss_hand_angle=1)
+        cfg.update(fittingconfig)
+        for key, val in cfg.items():
+            setattr(self, key, val)
+        self.device = torch.device(self.device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('saga_amd.motion_fitting.FittingOP runs on a ROCm GPU only (device=%s)' % self.device)
+        S, T = self.n_seq, self.T
+
+        def make(batch):
+            bm = _smplx.create(self.body_model_path, model_type='smplx', gender=self.gender, ext='npz', num_pca_comps=24,
+                               create_global_orient=True, create_body_pose=True, create_betas=True,
+                               create_left_hand_pose=True, create_right_hand_pose=True, create_expression=True,
+                               create_jaw_pose=True, create_leye_pose=True, create_reye_pose=True, create_transl=True,
+                               batch_size=batch, **self.smplx_kwargs)
+            return bm.to(self.device).eval()
+
+        self.smplx_model = make(S)                    # one frame of every sequence (stage 1)
+        self.smplx_model_batch = make(S * T)          # every frame of every sequence (stage 2)
+        if self.vposer is None:
+            self.vposer = VPoserDecoder(seed=0)
+        self.vposer_model = self.vposer.to(self.device).eval()
+        for p in self.vposer_model.parameters():
+            p.requires_grad_(False)
+        idx = self.indices if self.indices is not None else load_grasp_indices()
+        self.foot_groups = ml.foot_groups(idx)
+        as_ids = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.long, device=self.device)
+        self.markers_ids = as_ids(self.markers_ids)
+        self.markers_ids_143 = as_ids(self.markers_ids_143)
+        self.init_param_t()
+
+    # ---- variables -----------------------------------------------------------------------------------------------------
+    def init_param_t(self):
+        """``:40-55``: one frame's variables, here one row per sequence."""
+        S, dev = self.n_seq, self.device
+        transl = torch.zeros(S, 3, device=dev)
+        transl[:, 1] = 0.4
+        transl[:, 2] = 1.0
+        rot = torch.zeros(S, 3, device=dev)
+        rot[:, 1] = 1.6
+        rot[:, 2] = 3.14
+        self.transl_opt_t = transl.requires_grad_(True)
+        self.rot_6d_opt_t = convert_to_6D_all(rot).requires_grad_(True)
+        self.other_params_opt_t = torch.zeros(S, 56 + 24, device=dev, requires_grad=True)    # VPoser 32 + hands 24 + 24
+        self.shape_t = torch.as_tensor(np.asarray(self.smplx_beta), dtype=torch.float32, device=dev).reshape(S, -1)
+
+    def init_param_T(self, transl_opt_T, rot_6d_opt_T, other_params_opt_T, shape_T):
+        """``:57-61``: whole-sequence variables [S,T,.]."""
+        dev = self.device
+        self.transl_opt_T = transl_opt_T.to(dev).clone().requires_grad_(True)
+        self.rot_6d_opt_T = rot_6d_opt_T.to(dev).clone().requires_grad_(True)
+        self.other_params_opt_T = other_params_opt_T.to(dev).clone().requires_grad_(True)
+        self.shape_T = torch.as_tensor(shape_T, dtype=torch.float32, device=dev)
+
+    @staticmethod
+    def _set_lr(opt, lr):
+        for group in opt.param_groups:
+            group['lr'] = lr
+
+    # ---- stage 1 -------------------------------------------------------------------------------------------------------
+    def fitting_stage1(self, body_markers_rec):
+        """``:283-340``.  body_markers_rec [S,T,79,3] (or [T,79,3] when S = 1) -> transl [S,T,3], rot6d [S,T,6],
+        shape [S,T,10], other [S,T,80], markers [S,T,79,3]."""
+        S, T = self.n_seq, self.T
+        rec = torch.as_tensor(body_markers_rec).to(self.device).float().reshape(S, T, -1, 3)
+        self.optimizer_s1 = optim.Adam([self.transl_opt_t, self.rot_6d_opt_t, self.other_params_opt_t], lr=self.init_lr_stage1)
+        out = {k: [] for k in ('transl', 'rot', 'shape', 'other')}
+        w = self
+        for t in range(T):
+            markers_rec_t = rec[:, t]
+            if t > 0:
+                self._set_lr(self.optimizer_s1, 0.005)
+            for step in range(self.num_iter[0]):
+                if step > 60:
+                    self._set_lr(self.optimizer_s1, 0.01)
+                if step > 80:
+                    self._set_lr(self.optimizer_s1, 0.003)
+                self.optimizer_s1.zero_grad()
+                p = convert_to_3D_rot(torch.cat([self.transl_opt_t, self.rot_6d_opt_t, self.shape_t, self.other_params_opt_t], dim=-1))
+                verts, _ = gen_body_mesh_v1(p, self.smplx_model, self.vposer_model)
+                markers = verts.index_select(1, self.markers_ids)
+                loss_marker = (markers - markers_rec_t).abs().mean(dim=(1, 2))
+                loss = (w.stage1_weight_loss_rec_markers * loss_marker
+                        + w.stage1_weight_loss_vposer * (p[:, 16:48] ** 2).mean(dim=1)
+                        + w.stage1_weight_loss_shape * (p[:, 6:16] ** 2).mean(dim=1)
+                        + w.stage1_weight_loss_hand * (p[:, 48:] ** 2).mean(dim=1))
+                loss.sum().backward()
+                self.optimizer_s1.step()
+            out['transl'].append(self.transl_opt_t.detach().clone())
+            out['rot'].append(self.rot_6d_opt_t.detach().clone())
+            out['shape'].append(self.shape_t.detach().clone())
+            out['other'].append(self.other_params_opt_t.detach().clone())
+        st = lambda k: torch.stack(out[k], dim=1)
+        return st('transl'), st('rot'), st('shape'), st('other'), rec.clone()
+
+    # ---- stage 2 -------------------------------------------------------------------------------------------------------
+    def stage2_losses(self, markers_rec_T, markers_end_new, rhand_verts, contact_lbl_rec, contact_object, contact_markers,
+                      normal_object, verts_object):
+        """One evaluation of the stage-2 objective (``:356-409``) -> (total [S], dict of the weighted terms' raw values)."""
+        S, T, start_t, w = self.n_seq, self.T, self.start_t, self
+        p = convert_to_3D_rot(torch.cat([self.transl_opt_T, self.rot_6d_opt_T, self.shape_T, self.other_params_opt_T],
+                                        dim=-1).reshape(S * T, -1))
+        verts, _ = gen_body_mesh_v1(p, self.smplx_model_batch, self.vposer_model)
+        verts = verts.reshape(S, T, -1, 3)
+        markers = verts.index_select(2, self.markers_ids)
+        mask = torch.ones(1, 1, markers.shape[2], 1, device=self.device)
+        mask[:, :, 49:49 + 6] = 0        # hand
+        mask[:, :, 33:33 + 6] = 0        # forearm
+        mask[:, :, 69:] = 0              # finger
+        terms = {}
+        terms['rec_markers'] = (markers * mask - markers_rec_T * mask).abs().mean(dim=(1, 2, 3))
+        terms['end_markers_fit'] = (markers[:, -1] - markers_end_new).abs().mean(dim=(1, 2))
+        terms['skating'] = ml.skating_loss_seq(verts, contact_lbl_rec, self.foot_groups)
+        terms['contact'], state = ml.contact_loss_seq(self.smplx_model_batch, start_t, verts, self.markers_ids_143, rhand_verts,
+                                                       contact_object, contact_markers, normal_object, verts_object, n_frames=T)
+        terms['hand_smooth'] = ml.hand_smooth_loss_seq(verts, start_t, rhand_verts)
+        terms['collision'] = ml.collision_loss_seq(state)
+        terms['hand_angle'] = ml.angle_loss_seq(state, start_t, T)
+        pp = p.reshape(S, T, -1)
+        terms['vposer'] = (pp[:, :, 16:48] ** 2).mean(dim=(1, 2))
+        terms['hand'] = (pp[:, :, 48:] ** 2).mean(dim=(1, 2))
+        total = (w.stage2_weight_loss_rec_markers * terms['rec_markers']
+                 + w.stage2_weight_loss_end_markers_fit * terms['end_markers_fit']
+                 + w.stage2_weight_loss_vposer * terms['vposer']
+                 + w.stage2_weight_loss_hand * terms['hand']
+                 + w.stage2_weight_loss_skating * terms['skating']
+                 + w.stage2_weight_loss_hand_smooth * terms['hand_smooth']
+                 + w.stage2_weight_loss_collision * terms['collision']
+                 + w.stage2_weight_loss_contact * terms['contact']
+                 + w.stage2_weight_loss_hand_angle * terms['hand_angle'])
+        if self.body_smooth_loss is not None:
+            terms['smooth'] = self.body_smooth_loss(verts, pp)
+            total = total + w.stage2_weight_loss_smooth * terms['smooth']
+        return total, terms
+
+    def fitting_stage2(self, markers_rec_T, markers_end_new, rhand_verts, contact_lbl_rec, contact_object, contact_markers,
+                       normal_object, verts_object, record=None):
+        """``:342-414``.  markers_rec_T [S,T,79,3]; markers_end_new [S,79,3]; rhand_verts: 778 ids; contact_lbl_rec
+        [S,T,4]; contact_object [S,O]; contact_markers [S,143]; normal_object / verts_object [S,T-start_t,O,3]."""
+        S, T, dev = self.n_seq, self.T, self.device
+        f = lambda a, *shape: torch.as_tensor(a).to(dev).float().reshape(*shape)
+        markers_rec_T = f(markers_rec_T, S, T, -1, 3)
+        markers_end_new = f(markers_end_new, S, -1, 3)
+        contact_lbl_rec = f(contact_lbl_rec, S, T, 4)
+        contact_object, contact_markers = f(contact_object, S, -1), f(contact_markers, S, -1)
+        O = contact_object.shape[1]
+        normal_object, verts_object = f(normal_object, S, T - self.start_t, O, 3), f(verts_object, S, T - self.start_t, O, 3)
+        rhand_verts = torch.as_tensor(np.asarray(rhand_verts), dtype=torch.long, device=dev)
+        self.optimizer_s2 = optim.Adam([self.transl_opt_T, self.rot_6d_opt_T, self.other_params_opt_T], lr=self.init_lr_stage2)
+        for step in range(self.num_iter[1]):
+            if step > 150:
+                self._set_lr(self.optimizer_s2, 0.005)
+            self.optimizer_s2.zero_grad()
+            total, terms = self.stage2_losses(markers_rec_T, markers_end_new, rhand_verts, contact_lbl_rec, contact_object,
+                                              contact_markers, normal_object, verts_object)
+            total.sum().backward()
+            self.optimizer_s2.step()
+            if record is not None:
+                record(step, total.detach(), {k: v.detach() for k, v in terms.items()})
+        return self.transl_opt_T, self.rot_6d_opt_T, self.shape_T, self.other_params_opt_T
+
+    def fitting(self, body_markers_rec, markers_end_new, rhand_verts, contact_lbl_rec, contact_object, contact_markers,
+                normal_object, verts_object):
+        """``:417-428``: stage 1, then stage 2 from its result; returns both parameter sets."""
+        transl, rot, shape, other, markers_rec_T = self.fitting_stage1(body_markers_rec)
+        self.init_param_T(transl.detach(), rot.detach(), other.detach(), shape.detach())
+        final = self.fitting_stage2(markers_rec_T, markers_end_new, rhand_verts, contact_lbl_rec, contact_object,
+                                    contact_markers, normal_object, verts_object)
+        return (transl, rot, shape, other) + tuple(final)

@@ -108,6 +108,15 @@ def gen_indices():
     for marker in markerset:                                     # fittingop.py:92-95
         if marker['type'] not in ['palm_5']:
             markers_143 += list(marker['indices'].values())
+    markers_f0_p5 = []                                           # utils_body.py:311-329 with 'f0_p5' (opt_graspmotion.py:408)
+    for marker in markerset:
+        if marker['type'] == 'finger':
+            continue
+        if 'palm' in marker['type']:
+            if marker['type'] == 'palm_5':
+                markers_f0_p5 += list(marker['indices'].values())
+            continue
+        markers_f0_p5 += list(marker['indices'].values())
     raw = open(os.path.join(REF, 'body_utils/smplx_mano_flame_correspondences/MANO_SMPLX_vertex_ids.pkl'), 'rb').read()
     hands, key = {}, None
     for op, arg, _ in pickletools.genops(raw):
@@ -127,7 +136,8 @@ def gen_indices():
     foot_all = np.concatenate([foot['right_heel'], foot['right_toe'], foot['left_heel'], foot['left_toe']])  # :124
     w = np.load(os.path.join(REF, 'WholeGraspPose/configs/rhand_weight.npy'))
     path = os.path.join(HERE, 'grasp_indices.npz')
-    np.savez(path, markers_143=np.asarray(markers_143, dtype=np.int64), rhand=hands['right_hand'],
+    np.savez(path, markers_143=np.asarray(markers_143, dtype=np.int64),
+             markers_f0_p5=np.asarray(markers_f0_p5, dtype=np.int64), rhand=hands['right_hand'],
              lhand=hands['left_hand'], foot=foot_all.astype(np.int64), rhand_weight=w,
              foot_sizes=np.asarray([len(foot['right_heel']), len(foot['right_toe']),
                                     len(foot['left_heel']), len(foot['left_toe'])]))

@@ -82,3 +82,118 @@ def test_frames_as_batch_at_config4_size(body_model_dir):
         big = bm_big(return_verts=True, **ph)
         small = bm_small(return_verts=True, **{k: v[5 * T:6 * T] for k, v in ph.items()})
     assert torch.equal(big.vertices[5 * T:6 * T], small.vertices) and torch.equal(big.joints[5 * T:6 * T], small.joints)
+
+
+# ---- the two-stage driver (MotionFill/models/fittingop.py:283-428), S sequences per launch ------------------------------
+def _fit_problem(body_model_dir, S, Tn, start_t, seed=0):
+    """Targets from smooth synthetic motions: 79 markers per frame, an object next to the right hand of the last frame."""
+    from saga_amd.vposer import VPoserDecoder
+    idx = load_grasp_indices()
+    mk79 = torch.from_numpy(idx['markers_f0_p5']).long()
+    rh = torch.from_numpy(idx['rhand']).long()
+    bm_ref = load_oracle_model(body_model_dir, Tn, dtype=torch.float64)
+    g = torch.Generator().manual_seed(100 + seed)
+    prob = dict(markers_rec=[], markers_end=[], lbl=[], c_obj=[], c_mk=[], vo=[], no=[], beta=[])
+    vo, no, _, _ = make_object_cloud(S, seed=3 + seed)
+    for s in range(S):
+        a, b = random_body_inputs(1, seed=seed + 2 * s, scale=0.3), random_body_inputs(1, seed=seed + 2 * s + 1, scale=0.3)
+        lam = torch.linspace(0, 1, Tn, dtype=torch.float64)[:, None]
+        inp = {k: (1 - lam) * a[k] + lam * b[k] for k in a}
+        inp['transl'] = inp['transl'] * 0.05 + torch.tensor([0.0, 0.4, 1.0])
+        with torch.no_grad():
+            v = bm_ref(**inp)['vertices']
+        prob['markers_rec'].append(v[:, mk79])
+        prob['markers_end'].append(v[-1, mk79] + 0.01 * torch.randn(79, 3, generator=g, dtype=torch.float64))
+        prob['lbl'].append((torch.rand(Tn, 4, generator=g) > 0.4).double())
+        prob['c_obj'].append(torch.rand(2048, generator=g, dtype=torch.float64))
+        prob['c_mk'].append(torch.rand(143, generator=g, dtype=torch.float64))
+        o = torch.from_numpy(vo[s]).double()
+        o = o - o.mean(0) + v[-1, rh].mean(0)
+        prob['vo'].append(o[None].expand(Tn - start_t, -1, -1).contiguous())
+        prob['no'].append(torch.from_numpy(no[s]).double()[None].expand(Tn - start_t, -1, -1).contiguous())
+        prob['beta'].append(0.5 * torch.randn(10, generator=g, dtype=torch.float64))
+    prob = {k: torch.stack(v) for k, v in prob.items()}
+    vposer = VPoserDecoder(seed=0)
+    return idx, bm_ref, vposer, prob
+
+
+def _hip_op(body_model_dir, idx, vposer, prob, S, Tn, start_t, num_iter):
+    from saga_amd.motion_fitting import FittingOP
+    return FittingOP(dict(T=Tn, n_seq=S, start_t=start_t, gender='male', device='cuda', smplx_beta=prob['beta'].numpy(),
+                          num_iter=num_iter, markers_ids=idx['markers_f0_p5'], markers_ids_143=idx['markers_143'],
+                          body_model_path=body_model_dir, vposer=vposer, indices=idx))
+
+
+def test_motion_stage1_matches_oracle(body_model_dir):
+    """Per-frame marker fit, warm-started frame to frame: two sequences in one batch == two B=1 oracle runs."""
+    from oracle import motion_fit_ref as mfr
+    S, Tn, n1 = 2, 4, 4
+    idx, _, vposer, prob = _fit_problem(body_model_dir, S, Tn, 2)
+    op = _hip_op(body_model_dir, idx, vposer, prob, S, Tn, 2, [n1, 0])
+    transl, rot, shape, other, rec = op.fitting_stage1(prob['markers_rec'])
+    assert transl.shape == (S, Tn, 3) and rot.shape == (S, Tn, 6) and shape.shape == (S, Tn, 10) and other.shape == (S, Tn, 80)
+    bm1 = load_oracle_model(body_model_dir, 1, dtype=torch.float64)
+    w = vposer.weights_dict()
+    mk79 = torch.from_numpy(idx['markers_f0_p5']).long()
+    for s in range(S):
+        t_r, r_r, s_r, o_r = mfr.fitting_stage1(bm1, w, prob['beta'][s], mk79, prob['markers_rec'][s], n1)
+        # Adam's first steps are +-lr per element whatever the gradient's size: float32 vs float64 gradients agree in sign
+        # for every element here, so the trajectories stay within rounding of each other
+        for name, a, b in [('transl', transl[s], t_r), ('rot6d', rot[s], r_r), ('other', other[s], o_r)]:
+            np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), atol=2e-4, rtol=0, err_msg='%s seq %d' % (name, s))
+        np.testing.assert_allclose(shape[s].cpu().numpy(), s_r.numpy(), atol=1e-7)
+
+
+def test_motion_stage2_matches_oracle(body_model_dir):
+    """Whole-sequence stage: every loss term of the first iteration within 1e-4 of the oracle's, totals of the following
+    iterations within 5e-3 (the collision / skating / angle masks are discontinuous), for 2 sequences in one batch."""
+    from oracle import motion_fit_ref as mfr
+    S, Tn, start_t, n2 = 2, 13, 6, 4
+    idx, bm_ref, vposer, prob = _fit_problem(body_model_dir, S, Tn, start_t, seed=20)
+    groups = ml.foot_groups(idx)
+    mk79 = torch.from_numpy(idx['markers_f0_p5']).long()
+    mk143 = torch.from_numpy(idx['markers_143']).long()
+    rh = torch.from_numpy(idx['rhand']).long()
+    g = torch.Generator().manual_seed(9)
+    start = []
+    for s in range(S):     # a smooth start: transl near the targets, a constant orientation, small latent / hand values
+        lam = torch.linspace(0, 1, Tn, dtype=torch.float64)[:, None]
+        transl = torch.tensor([0.0, 0.4, 1.0], dtype=torch.float64) + 0.02 * lam
+        rot6 = mfr.convert_to_6D_all(torch.tensor([[0.0, 1.6, 3.14]], dtype=torch.float64)).expand(Tn, -1).contiguous()
+        other = 0.1 * torch.randn(1, 80, generator=g, dtype=torch.float64) + 0.05 * lam * torch.randn(1, 80, generator=g, dtype=torch.float64)
+        start.append((transl, rot6, prob['beta'][s][None].expand(Tn, -1).contiguous(), other))
+    op = _hip_op(body_model_dir, idx, vposer, prob, S, Tn, start_t, [0, n2])
+    st = lambda i: torch.stack([v[i] for v in start])
+    op.init_param_T(st(0).float(), st(1).float(), st(3).float(), st(2).float().numpy())
+    hist = []
+    out = op.fitting_stage2(prob['markers_rec'], prob['markers_end'], idx['rhand'], prob['lbl'], prob['c_obj'], prob['c_mk'],
+                            prob['no'], prob['vo'], record=lambda i, tot, terms: hist.append((tot.cpu(), {k: v.cpu() for k, v in terms.items()})))
+    faces = torch.from_numpy(bm_ref.faces.astype(np.int64))
+    w = vposer.weights_dict()
+    for s in range(S):
+        ref_hist = []
+        res = mfr.fitting_stage2(bm_ref, faces, w, groups, mk79, mk143, start[s], prob['markers_rec'][s], prob['markers_end'][s], rh,
+                                 prob['lbl'][s], prob['c_obj'][s][None], prob['c_mk'][s][None], prob['no'][s], prob['vo'][s], n2,
+                                 start_t=start_t, record=lambda i, tot, terms: ref_hist.append((tot, terms)))
+        for k, v in ref_hist[0][1].items():
+            np.testing.assert_allclose(hist[0][1][k][s].item(), v.item(), rtol=1e-4, atol=1e-9, err_msg='%s seq %d' % (k, s))
+        assert ref_hist[0][1]['contact'].item() > 0 and ref_hist[0][1]['skating'].item() > 0
+        for i in range(n2):
+            np.testing.assert_allclose(hist[i][0][s].item(), ref_hist[i][0].item(), rtol=1e-4 if i == 0 else 5e-3, err_msg='total it %d' % i)
+        for name, a, b in [('transl', out[0][s], res[0]), ('rot6d', out[1][s], res[1]), ('other', out[3][s], res[3])]:
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.numpy(), atol=2e-3, rtol=0, err_msg='%s seq %d' % (name, s))
+
+
+def test_motion_fitting_sequences_are_independent(body_model_dir):
+    """The batched driver gives each sequence the result of its own run: S = 2 equals two S = 1 runs up to the rounding
+    of the torch / rocBLAS pieces whose reduction order depends on the batch shape (VPoser linears, means)."""
+    S, Tn, start_t = 2, 7, 3
+    idx, _, vposer, prob = _fit_problem(body_model_dir, S, Tn, start_t, seed=40)
+    args = lambda sl: (prob['markers_rec'][sl], prob['markers_end'][sl], idx['rhand'], prob['lbl'][sl], prob['c_obj'][sl],
+                       prob['c_mk'][sl], prob['no'][sl], prob['vo'][sl])
+    both = _hip_op(body_model_dir, idx, vposer, prob, S, Tn, start_t, [2, 2]).fitting(*args(slice(0, 2)))
+    for s in range(S):
+        one_prob = {k: v[s:s + 1] for k, v in prob.items()}
+        one = _hip_op(body_model_dir, idx, vposer, one_prob, 1, Tn, start_t, [2, 2]).fitting(*args(slice(s, s + 1)))
+        for a, b in zip(both, one):
+            np.testing.assert_allclose(a[s].detach().cpu().numpy(), b[0].detach().cpu().numpy(), atol=2e-5, rtol=0)
