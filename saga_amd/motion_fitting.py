@@ -108,6 +108,7 @@ class FittingOP:
         as_ids = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.long, device=self.device)
         self.markers_ids = as_ids(self.markers_ids)
         self.markers_ids_143 = as_ids(self.markers_ids_143)
+        self._picker = None
         self.init_param_t()
 
     # ---- variables -----------------------------------------------------------------------------------------------------
@@ -175,6 +176,11 @@ class FittingOP:
         return st('transl'), st('rot'), st('shape'), st('other'), rec.clone()
 
     # ---- stage 2 -------------------------------------------------------------------------------------------------------
+    def _make_picker(self, rhand_verts):
+        sets = {'markers': self.markers_ids, 'markers_143': self.markers_ids_143, 'rhand': rhand_verts}
+        sets.update(self.foot_groups)
+        self._picker = ml.VertexPicker(sets, self.device)
+
     def stage2_losses(self, markers_rec_T, markers_end_new, rhand_verts, contact_lbl_rec, contact_object, contact_markers,
                       normal_object, verts_object):
         """One evaluation of the stage-2 objective (``:356-409``) -> (total [S], dict of the weighted terms' raw values)."""
@@ -183,7 +189,11 @@ class FittingOP:
                                         dim=-1).reshape(S * T, -1))
         verts, _ = gen_body_mesh_v1(p, self.smplx_model_batch, self.vposer_model)
         verts = verts.reshape(S, T, -1, 3)
-        markers = verts.index_select(2, self.markers_ids)
+        if self._picker is None:
+            self._make_picker(rhand_verts)
+        pk = self._picker
+        sub = pk.gather(verts)                                   # every vertex any term reads, gathered once
+        markers = sub.index_select(2, pk.pos['markers'])
         mask = torch.ones(1, 1, markers.shape[2], 1, device=self.device)
         mask[:, :, 49:49 + 6] = 0        # hand
         mask[:, :, 33:33 + 6] = 0        # forearm
@@ -191,10 +201,11 @@ class FittingOP:
         terms = {}
         terms['rec_markers'] = (markers * mask - markers_rec_T * mask).abs().mean(dim=(1, 2, 3))
         terms['end_markers_fit'] = (markers[:, -1] - markers_end_new).abs().mean(dim=(1, 2))
-        terms['skating'] = ml.skating_loss_seq(verts, contact_lbl_rec, self.foot_groups)
-        terms['contact'], state = ml.contact_loss_seq(self.smplx_model_batch, start_t, verts, self.markers_ids_143, rhand_verts,
-                                                       contact_object, contact_markers, normal_object, verts_object, n_frames=T)
-        terms['hand_smooth'] = ml.hand_smooth_loss_seq(verts, start_t, rhand_verts)
+        terms['skating'] = ml.skating_loss_seq(sub, contact_lbl_rec, {k: pk.pos[k] for k in self.foot_groups})
+        terms['contact'], state = ml.contact_loss_seq(self.smplx_model_batch, start_t, sub, pk.pos['markers_143'], pk.pos['rhand'],
+                                                       contact_object, contact_markers, normal_object, verts_object, n_frames=T,
+                                                       full_verts=verts, full_ids=(rhand_verts, self.markers_ids_143))
+        terms['hand_smooth'] = ml.hand_smooth_loss_seq(sub, start_t, pk.pos['rhand'])
         terms['collision'] = ml.collision_loss_seq(state)
         terms['hand_angle'] = ml.angle_loss_seq(state, start_t, T)
         pp = p.reshape(S, T, -1)
@@ -227,6 +238,7 @@ class FittingOP:
         O = contact_object.shape[1]
         normal_object, verts_object = f(normal_object, S, T - self.start_t, O, 3), f(verts_object, S, T - self.start_t, O, 3)
         rhand_verts = torch.as_tensor(np.asarray(rhand_verts), dtype=torch.long, device=dev)
+        self._make_picker(rhand_verts)
         self.optimizer_s2 = optim.Adam([self.transl_opt_T, self.rot_6d_opt_T, self.other_params_opt_T], lr=self.init_lr_stage2)
         for step in range(self.num_iter[1]):
             if step > 150:

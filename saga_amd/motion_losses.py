@@ -24,17 +24,36 @@ def foot_groups(idx):
     return out
 
 
+class VertexPicker:
+    """One gather of the union of several vertex-id sets out of [S,T,V,3] vertices, then cheap picks out of the small
+    result: the backward pass scatters into (and zero-fills, and accumulates) the full-size gradient once instead of
+    once per set -- at 256 x 61 bodies each of those is a 2 GB round trip."""
+
+    def __init__(self, sets, device):
+        ids = {k: torch.as_tensor(v, dtype=torch.long, device=device) for k, v in sets.items()}
+        self.union = torch.unique(torch.cat(list(ids.values())))                       # sorted
+        self.pos = {k: torch.searchsorted(self.union, v) for k, v in ids.items()}      # position of each id in the union
+        self.ids = ids
+
+    def gather(self, body_verts):
+        return body_verts.index_select(2, self.union)
+
+
 def contact_loss_seq(bm, start_t, body_verts, markers_143, rhand_verts, contact_object, contact_markers, normal_object,
-                     verts_object, n_frames=None):
+                     verts_object, n_frames=None, full_verts=None, full_ids=None):
     """body_verts [S,T,V,3]; verts_object / normal_object [S,T-start_t,O,3]; contact_object [S,O];
-    contact_markers [S,143] -> (loss [S], state)."""
-    S, T, V, _ = body_verts.shape
+    contact_markers [S,143] -> (loss [S], state).  With ``full_verts`` [S,T,V,3] and ``full_ids`` = (rhand ids, 143
+    marker ids) in the full mesh, ``body_verts`` may be a :class:`VertexPicker` gather and ``markers_143`` /
+    ``rhand_verts`` positions in it: the normals are then computed from ``full_verts``."""
+    S, T = body_verts.shape[:2]
     n_frames = T if n_frames is None else n_frames            # the reference hard-codes 61
     n_tail = T - start_t
-    tail = body_verts[:, start_t:].reshape(S * n_tail, V, 3)
-    palm = markers_143[-22:]                                   # right-hand palm markers (:133)
-    sel = torch.cat([rhand_verts, palm]).to(torch.int32)
-    normals = vertex_normals_subset(bm, tail, sel)             # only the rows the loss reads, every frame, on the device
+    tail = body_verts[:, start_t:].reshape(S * n_tail, -1, 3)
+    if full_verts is None:
+        full_verts, full_ids = body_verts, (rhand_verts, markers_143)
+    full_tail = full_verts[:, start_t:].reshape(S * n_tail, -1, 3)
+    sel = torch.cat([full_ids[0], full_ids[1][-22:]]).to(torch.int32)          # right hand + its 22 palm markers (:133)
+    normals = vertex_normals_subset(bm, full_tail, sel)        # only the rows the loss reads, every frame, on the device
     n_rh = rhand_verts.shape[0]
     rh_normals_full, rh_normals = normals[:, :n_rh], normals[:, n_rh:]
     body_markers = tail.index_select(1, markers_143)
