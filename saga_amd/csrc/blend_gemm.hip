@@ -44,7 +44,10 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // BKT  : k-depth of one LDS tile (16 or 32); NST: LDS stages (NST-1 tiles in flight beside the one being multiplied)
 // WT   : 32x32 MFMA tiles per wave and dimension: 2 -> 128x128 block tile (the blend contraction), 1 -> 64x64 (the small
 //        decoder layers, which need 4x the blocks to fill 256 CUs)
-template <int EPI, int BKT, int NST, int WT = 2>
+// TRS  : accumulate the TRANSPOSED 32x32 tiles (MFMA operands swapped; same products, same order, same bits): a lane then
+//        holds 4 consecutive output columns per register quad and the epilogue is 16 dwordx4 stores per wave instead of
+//        64 dword stores -- the store issue of a 128x128 tile was ~8 % of its time with K = 512
+template <int EPI, int BKT, int NST, int WT = 2, bool TRS = true>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ Bt, int ldb, float* __restrict__ C,
                                                           int ldc, const float* __restrict__ bias,
@@ -139,10 +142,17 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
             for (int mt = 0; mt < WT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < WT; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].x, bf[g][nt].x, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].y, bf[g][nt].y, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].z, bf[g][nt].z, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].w, bf[g][nt].w, acc[mt][nt], 0, 0, 0);
+                    if (TRS) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].x, af[g][mt].x, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].y, af[g][mt].y, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].z, af[g][mt].z, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].w, af[g][mt].w, acc[mt][nt], 0, 0, 0);
+                    } else {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].x, bf[g][nt].x, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].y, bf[g][nt].y, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].z, bf[g][nt].z, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].w, bf[g][nt].w, acc[mt][nt], 0, 0, 0);
+                    }
                 }
         }
     }
@@ -151,6 +161,39 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     float* Cz = C;
     if (EPI == 1) Cz += (size_t)blockIdx.z * M * ldc;
     const bool full = (m0 + TBM <= M);       // N is always a multiple of BN here (Npad / 512)
+    if (TRS) {
+        // transposed tiles: row = lane&31, col = (r&3) + 8*(r>>2) + 4*(lane>>5): one 16-B store per register quad
+#pragma unroll
+        for (int mt = 0; mt < WT; ++mt) {
+            const int row = m0 + wm * 32 * WT + mt * 32 + l31;
+            if (!full && row >= M) continue;
+#pragma unroll
+            for (int nt = 0; nt < WT; ++nt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = n0 + wn * 32 * WT + nt * 32 + 8 * q + 4 * half;
+                    if (col >= N) continue;
+                    const size_t off = (size_t)row * ldc + col;
+                    float4 v = make_float4(acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]);
+                    if ((EPI == 0 || EPI == 2) && bias) {
+                        const float4 bv = *reinterpret_cast<const float4*>(bias + col);
+                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    }
+                    if (EPI == 2) {
+                        v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y;
+                        v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w;
+                    }
+                    if (EPI == 3) {
+                        const float4 x = *reinterpret_cast<const float4*>(aux + off);
+                        v.x = x.x > 0.f ? v.x : 0.2f * v.x; v.y = x.y > 0.f ? v.y : 0.2f * v.y;
+                        v.z = x.z > 0.f ? v.z : 0.2f * v.z; v.w = x.w > 0.f ? v.w : 0.2f * v.w;
+                    }
+                    *reinterpret_cast<float4*>(Cz + off) = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < WT; ++nt) {
         const int col = n0 + wn * 32 * WT + nt * 32 + l31;

@@ -12,12 +12,12 @@ void saga_set_error(const char*, ...) {}
 
 typedef void (*launch_t)(const float*, const float*, float*, const float*, int, int, int, int, hipStream_t);
 
-template <int EPI, int BKT, int NST>
+template <int EPI, int BKT, int NST, bool TRS = true>
 void launch(const float* A, const float* Bt, float* C, const float* bias, int M, int N, int K, int splitk, hipStream_t st) {
     const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
     const int kchunk = splitk == 1 ? K : ((K + splitk - 1) / splitk + 31) / 32 * 32;
     dim3 grid(tiles_m * tiles_n, 1, splitk);
-    gemm_nt_f32_kernel<EPI, BKT, NST><<<grid, 256, 0, st>>>(A, K, Bt, K, C, N, bias, M, N, K, kchunk, tiles_m);
+    gemm_nt_f32_kernel<EPI, BKT, NST, 2, TRS><<<grid, 256, 0, st>>>(A, K, Bt, K, C, N, bias, nullptr, M, N, K, kchunk, tiles_m);
 }
 
 struct Var { const char* name; launch_t f0; launch_t f1; };
@@ -39,15 +39,12 @@ int main() {
     G = Cref; Bk = Bt;
     CK(hipMalloc(&slab, (size_t)16 * M * 512 * 4));
     Var vars[] = {
-        {"bk32_st2", launch<0, 32, 2>, launch<1, 32, 2>},
-        {"bk16_st2", launch<0, 16, 2>, launch<1, 16, 2>},
-        {"bk16_st3", launch<0, 16, 3>, launch<1, 16, 3>},
-        {"bk16_st4", launch<0, 16, 4>, launch<1, 16, 4>},
-        {"bk32_st3", launch<0, 32, 3>, launch<1, 32, 3>},
-        {"bk32_st4", launch<0, 32, 4>, launch<1, 32, 4>},
-        {"bk16_st5", launch<0, 16, 5>, launch<1, 16, 5>},
-        {"bk16_st6", launch<0, 16, 6>, launch<1, 16, 6>},
-        {"bk16_st8", launch<0, 16, 8>, launch<1, 16, 8>},
+        {"st4_dword", launch<0, 16, 4, false>, launch<1, 16, 4, false>},
+        {"st4_x4", launch<0, 16, 4, true>, launch<1, 16, 4, true>},
+        {"st5_dword", launch<0, 16, 5, false>, launch<1, 16, 5, false>},
+        {"st5_x4", launch<0, 16, 5, true>, launch<1, 16, 5, true>},
+        {"st3_x4", launch<0, 16, 3, true>, launch<1, 16, 3, true>},
+        {"st6_x4", launch<0, 16, 6, true>, launch<1, 16, 6, true>},
     };
     const int NV = sizeof(vars) / sizeof(vars[0]);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
