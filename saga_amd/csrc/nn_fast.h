@@ -5,14 +5,16 @@
 // centred on its own bounding box and stored as (-2x, -2y, -2z, |p|^2); then
 //        t(p) = fma(qz, -2z, fma(qy, -2y, fma(qx, -2x, |p|^2)))  =  |q - p|^2 - |q|^2  + rounding
 // costs 3 fmas per pair (two pairs per v_pk_fma_f32), and |q|^2 is the same for every p so argmin t = argmin distance
-// up to the rounding error, for which a rigorous bound E is carried (below).  Points are visited in chunks of 16; a
+// up to the rounding error, for which a rigorous bound E is carried (below).  Points are visited in chunks of NNF_CH; a
 // query keeps the three smallest chunk minima (m1 <= m2 <= m3) and the chunks (c1, c2) of the first two.
 //   * every point whose EXACT distance could be the minimum lies in a chunk with chunk-minimum <= m1 + margin;
-//   * if m3 > m1 + margin those chunks are c1 and c2 only: their 32 points are re-evaluated with the exact arithmetic
+//   * if m3 > m1 + margin those chunks are c1 and c2 only: their 2 x NNF_CH points are re-evaluated with the exact arithmetic
 //     of nn_scan.h (original coordinates, index order, strict '<') -- bit-identical to the sequential exact scan;
 //   * otherwise (three or more chunks inside the margin: ~1e-3 of the queries) the query takes a slow path that
 //     re-evaluates every chunk inside the margin exactly.
 // So the result is ALWAYS that of the exact scan (lowest index among the exact minima), never an approximation.
+// Cost split measured on the fused loss kernel (B = 4096, 1.46 ms): approximate pass 1.24 ms, exact pass of the two
+// candidate chunks 0.16 ms, slow path 0.06 ms (a wave runs it when any of its 64 lanes needs it).
 //
 // Frame: per axis c = the bounding box's midpoint if the box satisfies hi <= 2 lo (same sign), else 0.  Then p/2 <= c <=
 // 2p for every point, so p - c is exact (Sterbenz) and p = fma(-0.5, -2(p - c), c) recovers the original coordinate
@@ -26,9 +28,12 @@
 #pragma once
 #include "nn_scan.h"
 
-#define NNF_CH 16
-#define NNF_CSTRIDE 68    // floats per chunk: 8 point pairs x {x0,x1,y0,y1,z0,z1,w0,w1} + 4 pad (per-lane chunk reads of the
-                          // exact pass then start on 16 different bank groups instead of one)
+#ifndef NNF_CH
+#define NNF_CH 16         // points per chunk (a multiple of 8).  Measured on the fused loss kernel: 16 -> 1.47 ms, 32 -> 1.64 ms (the
+                          // sorted insert is amortised over more pairs, but the exact pass re-evaluates 2 x NNF_CH points)
+#endif
+#define NNF_CSTRIDE (NNF_CH * 4 + 4)   // floats per chunk: NNF_CH/2 point pairs x {x0,x1,y0,y1,z0,z1,w0,w1} + 4 pad (per-lane
+                          // chunk reads of the exact pass then start on different bank groups instead of one)
 #define NNF_TILE_FLOATS(n) (((n) + NNF_CH - 1) / NNF_CH * NNF_CSTRIDE)
 
 struct NnfFrame { float cx, cy, cz, rp; };
@@ -87,7 +92,7 @@ __device__ __forceinline__ NnfFrame nnf_frame(const float* __restrict__ src, int
 __device__ __forceinline__ void nnf_store_point(float* __restrict__ s, int k, float x, float y, float z, const NnfFrame& f) {
     const float px = x - f.cx, py = y - f.cy, pz = z - f.cz;       // exact for points inside the frame's box
     const float w = __builtin_fmaf(pz, pz, __builtin_fmaf(py, py, px * px));
-    float* d = s + (k >> 4) * NNF_CSTRIDE + ((k & 15) >> 1) * 8 + (k & 1);
+    float* d = s + (k / NNF_CH) * NNF_CSTRIDE + ((k % NNF_CH) >> 1) * 8 + (k & 1);
     d[0] = -2.f * px; d[2] = -2.f * py; d[4] = -2.f * pz; d[6] = w;
 }
 
@@ -105,7 +110,7 @@ __device__ __forceinline__ int nnf_stage_tile(float* __restrict__ s, const float
 
 // original coordinates of point j of a framed tile (bit-exact)
 __device__ __forceinline__ void nnf_tile_point(const float* __restrict__ s, const NnfFrame& f, int j, float& x, float& y, float& z) {
-    const float* p = s + (j >> 4) * NNF_CSTRIDE + ((j & 15) >> 1) * 8 + (j & 1);
+    const float* p = s + (j / NNF_CH) * NNF_CSTRIDE + ((j % NNF_CH) >> 1) * 8 + (j & 1);
     x = __builtin_fmaf(-0.5f, p[0], f.cx); y = __builtin_fmaf(-0.5f, p[2], f.cy); z = __builtin_fmaf(-0.5f, p[4], f.cz);
 }
 
@@ -118,7 +123,7 @@ __device__ __forceinline__ void nnf_scan(const float* __restrict__ s, int n_chun
     for (int i = 0; i < NQ; ++i) { m1[i] = INFINITY; m2[i] = INFINITY; m3[i] = INFINITY; c1[i] = -1; c2[i] = -1; }
     // One step = two point pairs (4 points, 4 broadcast ds_read_b128) against the NQ queries: 2*NQ independent chains of
     // three v_pk_fma_f32, issued stage by stage.  Steps are software-pipelined through two register sets (A, B): the
-    // reads of step g+1 are in flight while step g computes; a chunk is four steps (A,B,A,B), so the set that holds the
+    // reads of step g+1 are in flight while step g computes; a chunk is an even number of steps (A,B,...,A,B), so the set that holds the
     // next chunk's first step at the loop's back edge is A again and no register moves are needed.
     auto load4 = [&](float4 (&r)[4], int c, int g) {
         const float4* t = reinterpret_cast<const float4*>(s + c * NNF_CSTRIDE) + 4 * g;
@@ -158,18 +163,16 @@ __device__ __forceinline__ void nnf_scan(const float* __restrict__ s, int n_chun
     for (int c = 0; c < n_chunks; ++c) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) m[i] = INFINITY;
-        load4(B, c, 1);
-        step(A);
-        __builtin_amdgcn_sched_barrier(0);
-        load4(A, c, 2);
-        step(B);
-        __builtin_amdgcn_sched_barrier(0);
-        load4(B, c, 3);
-        step(A);
-        __builtin_amdgcn_sched_barrier(0);
-        load4(A, min(c + 1, n_chunks - 1), 0);
-        step(B);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < NNF_CH / 4; g += 2) {
+            load4(B, c, g + 1);
+            step(A);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 2 < NNF_CH / 4) load4(A, c, g + 2);
+            else load4(A, min(c + 1, n_chunks - 1), 0);
+            step(B);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             // sorted insert of m into (m1 <= m2 <= m3), chunks of the first two (selects, no branches)
