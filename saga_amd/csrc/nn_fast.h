@@ -212,7 +212,8 @@ __device__ __forceinline__ void nnf_exact_chunk(const float* __restrict__ s, con
 
 // Exact pass.  qc*: framed queries (for the margin), o*: original query coordinates.  best/bi (IN/OUT; the caller
 // starts them at +INF / 0): exact squared distance and index of the sequential exact scan over every tile so far
-// (global index of point 0 of this tile = base; tiles must come in index order).
+// (global index of point 0 of this tile = base; tiles must come in index order).  Every lane of the wave must call it
+// together (the slow path is a wave-wide loop).
 template <int NQ>
 __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_chunks, const NnfFrame& f, int base,
                                             const float (&qx)[NQ], const float (&qy)[NQ], const float (&qz)[NQ],
@@ -220,6 +221,7 @@ __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_c
                                             const float (&m1)[NQ], const float (&m2)[NQ], const float (&m3)[NQ],
                                             const int (&c1)[NQ], const int (&c2)[NQ],
                                             float (&best)[NQ], int (&bi)[NQ]) {
+    const int lane = __lane_id();
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const float qq = __builtin_fmaf(qz[i], qz[i], __builtin_fmaf(qy[i], qy[i], qx[i] * qx[i])) * 1.001f;
@@ -227,8 +229,9 @@ __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_c
         const float thr = m1[i] + (2.f * E + 1.0e-6f * (fmaxf(m1[i] + qq, 0.f) + E));
         // a tile whose best possible distance cannot beat the exact minimum carried in from earlier tiles is skipped:
         // D(p) >= t(p) - E + |q - c|^2 (1 - 3u) for every point of this tile, and its fp32 distance is >= D (1 - 6u)
-        if (m1[i] - E + qq * 0.998f > best[i] * 1.000001f) continue;
-        if (m3[i] > thr) {
+        const bool live = !(m1[i] - E + qq * 0.998f > best[i] * 1.000001f);
+        const bool fast = live && m3[i] > thr;
+        if (fast) {
             // the exact winner is in chunk c1 or c2: lower chunk first so that ties keep the lowest index
             // (c2 only matters when its minimum is inside the margin)
             const bool two = c2[i] >= 0 && m2[i] <= thr;
@@ -236,20 +239,42 @@ __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_c
             const int b = two ? max(c1[i], c2[i]) : c1[i];
             nnf_exact_chunk(s, f, a, base, ox[i], oy[i], oz[i], best[i], bi[i]);
             if (b != a) nnf_exact_chunk(s, f, b, base, ox[i], oy[i], oz[i], best[i], bi[i]);
-        } else {
-            // slow path: every chunk whose approximate minimum is inside the margin, in index order
-            for (int c = 0; c < n_chunks; ++c) {
+        }
+        // slow path (three or more chunks inside the margin), one query at a time with the whole wave: lane l takes
+        // chunks l, l+64, ..., re-evaluates those whose approximate minimum is inside the margin exactly (ascending, strict
+        // '<'), and the lanes' (distance, index) pairs are reduced lexicographically -- the lowest index among the exact
+        // minima of the tile, as a sequential scan finds it.  (Per lane this loop would cost a third of a whole scan each
+        // time one of 64 lanes needs it.)
+        unsigned long long todo = __ballot(live && !fast);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const float sqx = __shfl(qx[i], src, 64), sqy = __shfl(qy[i], src, 64), sqz = __shfl(qz[i], src, 64);
+            const float sox = __shfl(ox[i], src, 64), soy = __shfl(oy[i], src, 64), soz = __shfl(oz[i], src, 64);
+            const float sthr = __shfl(thr, src, 64);
+            float cb = INFINITY;
+            int ci = 0x7fffffff;
+            for (int c = lane; c < n_chunks; c += 64) {
                 const float4* t = reinterpret_cast<const float4*>(s + c * NNF_CSTRIDE);
                 float m = INFINITY;
 #pragma unroll
                 for (int g = 0; g < NNF_CH / 2; ++g) {
                     const float4 a = t[2 * g], b = t[2 * g + 1];
-                    const float v0 = __builtin_fmaf(qz[i], b.x, __builtin_fmaf(qy[i], a.z, __builtin_fmaf(qx[i], a.x, b.z)));
-                    const float v1 = __builtin_fmaf(qz[i], b.y, __builtin_fmaf(qy[i], a.w, __builtin_fmaf(qx[i], a.y, b.w)));
+                    const float v0 = __builtin_fmaf(sqz, b.x, __builtin_fmaf(sqy, a.z, __builtin_fmaf(sqx, a.x, b.z)));
+                    const float v1 = __builtin_fmaf(sqz, b.y, __builtin_fmaf(sqy, a.w, __builtin_fmaf(sqx, a.y, b.w)));
                     m = __builtin_fminf(__builtin_fminf(m, v0), v1);
                 }
-                if (m <= thr) nnf_exact_chunk(s, f, c, base, ox[i], oy[i], oz[i], best[i], bi[i]);
+                if (m <= sthr) nnf_exact_chunk(s, f, c, base, sox, soy, soz, cb, ci);
             }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(cb, o, 64);
+                const int oi = __shfl_xor(ci, o, 64);
+                const bool take = ob < cb || (ob == cb && oi < ci);
+                cb = take ? ob : cb;
+                ci = take ? oi : ci;
+            }
+            if (lane == src && cb < best[i]) { best[i] = cb; bi[i] = ci; }
         }
     }
 }
