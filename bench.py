@@ -233,7 +233,7 @@ def main():
                          'traffic_note': 'HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/); '
                                          'algorithmic bytes per launch = %d' % int(B * 3 * V * 4 + B * 512 * 4 + 3 * V * 512 * 4)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only (host cores are shared by the ranks)
             cand_per_s, threads, dt = cpu_baseline(tmp.name, vp, n_obj, args.cpu_batch, args.cpu_iters)
             out['cpu_baseline'] = {
                 'value': round(cand_per_s / B, 6), 'unit': 'iterations/s at B=%d (extrapolated from candidate-iterations/s)' % B,

@@ -299,6 +299,18 @@ class FittingOP:
             self._decoder = (key, out)
         return self._decoder[1]
 
+    def close(self):
+        """Release the decoder constants held by the library (also done when the object is collected)."""
+        dec, self._decoder = getattr(self, '_decoder', None), None
+        if dec is not None:
+            try:
+                _lib.load().saga_decoder_destroy(dec[1])
+            except Exception:      # interpreter shutdown: the library may already be gone
+                pass
+
+    def __del__(self):
+        self.close()
+
     def _workspace(self, n_obj):
         n = _lib.load().saga_fit_workspace_floats(self.bm.handle(self.device), ctypes.byref(self.tables.struct), self.batch_size, n_obj)
         if self._ws is None or self._ws.numel() < n:
