@@ -197,3 +197,23 @@ def test_motion_fitting_sequences_are_independent(body_model_dir):
         one = _hip_op(body_model_dir, idx, vposer, one_prob, 1, Tn, start_t, [2, 2]).fitting(*args(slice(s, s + 1)))
         for a, b in zip(both, one):
             np.testing.assert_allclose(a[s].detach().cpu().numpy(), b[0].detach().cpu().numpy(), atol=2e-5, rtol=0)
+
+
+def test_motion_opt_result_schema(body_model_dir, tmp_path):
+    """``saved_results`` of opt_graspmotion.py:549-561: keys, nesting and [S,T,.] shapes; the file loads back."""
+    from saga_amd.opt_graspmotion import BODY_KEYS, motion_opt
+    S, Tn, start_t = 2, 5, 2
+    idx, _, vposer, prob = _fit_problem(body_model_dir, S, Tn, start_t, seed=60)
+    op = _hip_op(body_model_dir, idx, vposer, prob, S, Tn, start_t, [1, 1])
+    out = motion_opt(op, prob['markers_rec'], prob['markers_end'], idx['rhand'], prob['lbl'], prob['c_obj'], prob['c_mk'],
+                     prob['no'], prob['vo'], 'camera', np.zeros((S, Tn, 3), np.float32), np.zeros((S, Tn, 3, 3), np.float32),
+                     save_dir=str(tmp_path))
+    assert set(out) == {'body_orig', 'body_opt', 'object_name', 'object'} and set(out['object']) == {'transl', 'global_orient'}
+    dims = {'transl': 3, 'global_orient': 3, 'betas': 10, 'body_pose': 63, 'left_hand_pose': 24, 'right_hand_pose': 24}
+    for part in ('body_orig', 'body_opt'):
+        assert list(out[part]) == BODY_KEYS
+        for k, n in dims.items():
+            assert out[part][k].shape == (S, Tn, n) and np.isfinite(out[part][k]).all()
+    np.testing.assert_allclose(out['body_opt']['betas'], np.broadcast_to(prob['beta'].numpy()[:, None], (S, Tn, 10)), rtol=1e-6)
+    back = np.load(str(tmp_path / 'fitting_results.npy'), allow_pickle=True).item()
+    assert back['object_name'] == 'camera' and back['body_opt']['body_pose'].shape == (S, Tn, 63)
