@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void skin_bwd_dA_kernel(const float* __restric
                                                           const float* __restrict__ Wd, float* __restrict__ dA,
                                                           const float* __restrict__ A, const int32_t* __restrict__ w_idx,
                                                           const float* __restrict__ w_val, float* __restrict__ g_vposed, int B,
-                                                          int V, int Npad, int dA_stride) {
+                                                          int V, int Npad, int dA_stride, size_t part_stride) {
     // 24 KB of LDS (+ 10.6 KB of skinning transforms when fused; 4 blocks = 16 waves per CU): per-wave staging tiles
     // first, then (after a barrier) the two 12 KB slots of the cross-wave reduction
     __shared__ __attribute__((aligned(16))) float smem[2 * 12 * 64 * 4 + (FUSE ? DA_CANDS * NJ * 12 : 0)];
@@ -272,10 +272,14 @@ __global__ __launch_bounds__(256) void skin_bwd_dA_kernel(const float* __restric
     // per wave staging: [cand][vertex][8]: g(3), vp(3), 1, pad
     float* sXw = smem + wave * (DA_CANDS * DA_XSTRIDE);
     const int b0 = blockIdx.x * DA_CANDS;
-    // this wave's range of 16-vertex steps
+    // this block's share of the 16-vertex steps (blockIdx.y of gridDim.y vertex ranges: partial sums go to slab
+    // blockIdx.y of dA and are added in slab order by da_sum_kernel), and this wave's quarter of it
     const int n_steps = (V + DA_STEP - 1) / DA_STEP;
-    const int per_wave = (n_steps + 3) / 4;
-    const int s_begin = wave * per_wave, s_end = min(n_steps, s_begin + per_wave);
+    const int per_block = (n_steps + gridDim.y - 1) / gridDim.y;
+    const int blk_begin = blockIdx.y * per_block, blk_end = min(n_steps, blk_begin + per_block);
+    const int per_wave = (max(blk_end - blk_begin, 0) + 3) / 4;
+    const int s_begin = blk_begin + wave * per_wave, s_end = min(blk_end, s_begin + per_wave);
+    dA += blockIdx.y * part_stride;
 
     // A-operand role of this lane: row i = lane&15 of M-tile mt -> (cand, rc) ; k = lane>>4 -> vertex within the 4-group
     const int kq = lane >> 4, i16 = lane & 15;
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256) void skin_bwd_dA_kernel(const float* __restric
             sA[i] = A[(size_t)min(b0 + cd, B - 1) * (NJ * 12) + (i - cd * NJ * 12)];
         }
         // pad columns [3V, Npad) of g_v_posed (the split-K GEMM reads them)
-        if (wave == 0 && b0 + st_cd < B)
+        if (wave == 0 && blockIdx.y == 0 && b0 + st_cd < B)
             for (int c = 3 * V + st_v; c < Npad; c += 16) g_vposed[(size_t)(b0 + st_cd) * Npad + c] = 0.f;
         __syncthreads();
     }
@@ -463,22 +467,52 @@ int saga_launch_joints_bwd(const saga_model* m, const float* g_joints, float* g_
     return 0;
 }
 
+// dA[b][i] = sum of the vertex-range partials, in slab order (fixed -> bit-reproducible); i < DA_ROWS*12 only: the rest of a
+// dA row belongs to the joint gradients
+__global__ void da_sum_kernel(const float* __restrict__ part, float* __restrict__ dA, int B, int dA_stride, int n_parts, size_t part_stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * (DA_ROWS * 12)) return;
+    const int b = i / (DA_ROWS * 12), c = i - b * (DA_ROWS * 12);
+    const size_t off = (size_t)b * dA_stride + c;
+    float acc = part[off];
+    for (int p = 1; p < n_parts; ++p) acc += part[p * part_stride + off];
+    dA[off] = acc;
+}
+
+// scratch: >= 9 * B * dA_stride floats, free for the duration of the call (the split-K slabs, written later), or NULL
 int saga_launch_skin_bwd(const saga_model* m, const float* A, const float* g_verts, const float* v_posed, float* g_vposed,
-                         float* dA, int dA_stride, int B, hipStream_t st) {
+                         float* dA, int dA_stride, float* scratch, int B, hipStream_t st) {
     const int per_block = SKIN_THREADS * SKIN_VPT;
     dim3 grid1((m->Npad / 3 + 1 + per_block - 1) / per_block, B);     // covers every column of [0, Npad)
     const int blocks = (B + DA_CANDS - 1) / DA_CANDS;
+    // three vertex ranges per candidate group: 3 x (B/4) blocks of a third of the length fill the 3 blocks/CU evenly (B = 4096:
+    // 3072 blocks = 4 full rounds instead of 1 1/3) and keep small batches from leaving the chip idle
+    const int n_steps = (m->V + DA_STEP - 1) / DA_STEP;
+    int parts = 1;
+    if (scratch && n_steps >= 48) {
+        parts = 3;
+        if (blocks * parts < 768) parts = min((768 + blocks - 1) / blocks, 9);     // small batches: up to 9 ranges (scratch holds 9)
+        parts = max(1, min(parts, n_steps / 16));
+    }
+    const size_t part_stride = (size_t)B * dA_stride;
+    float* out = parts > 1 ? scratch : dA;
+    dim3 grid(blocks, parts);
     if (m->KW == 4) {
         // one pass: dA reduction on the matrix cores + g_v_posed on the vector units
-        skin_bwd_dA_kernel<true><<<blocks, 256, 0, st>>>(g_verts, v_posed, m->Wd, dA, A, m->w_idx, m->w_val, g_vposed, B, m->V, m->Npad,
-                                                         dA_stride);
+        skin_bwd_dA_kernel<true><<<grid, 256, 0, st>>>(g_verts, v_posed, m->Wd, out, A, m->w_idx, m->w_val, g_vposed, B, m->V, m->Npad,
+                                                       dA_stride, part_stride);
         SAGA_LAUNCH_CHECK();
-        return 0;
+    } else {
+        skin_bwd_vposed_kernel<false><<<grid1, SKIN_THREADS, 0, st>>>(A, g_verts, m->w_idx, m->w_val, g_vposed, m->V, m->Npad, m->KW);
+        SAGA_LAUNCH_CHECK();
+        skin_bwd_dA_kernel<false><<<grid, 256, 0, st>>>(g_verts, v_posed, m->Wd, out, nullptr, nullptr, nullptr, nullptr, B, m->V, m->Npad,
+                                                        dA_stride, part_stride);
+        SAGA_LAUNCH_CHECK();
     }
-    skin_bwd_vposed_kernel<false><<<grid1, SKIN_THREADS, 0, st>>>(A, g_verts, m->w_idx, m->w_val, g_vposed, m->V, m->Npad, m->KW);
-    SAGA_LAUNCH_CHECK();
-    skin_bwd_dA_kernel<false><<<blocks, 256, 0, st>>>(g_verts, v_posed, m->Wd, dA, nullptr, nullptr, nullptr, nullptr, B, m->V, m->Npad,
-                                                      dA_stride);
-    SAGA_LAUNCH_CHECK();
+    if (parts > 1) {
+        const int n = B * (DA_ROWS * 12);
+        da_sum_kernel<<<(n + 255) / 256, 256, 0, st>>>(scratch, dA, B, dA_stride, parts, part_stride);
+        SAGA_LAUNCH_CHECK();
+    }
     return 0;
 }

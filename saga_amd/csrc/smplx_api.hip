@@ -15,7 +15,7 @@ int saga_launch_joints_fwd(const saga_model* m, const float* chain, const float*
 int saga_launch_joints_bwd(const saga_model* m, const float* g_joints, float* g_pj, float* g_jsum, float* gv, int B,
                            int small_stride, hipStream_t st);
 int saga_launch_skin_bwd(const saga_model* m, const float* A, const float* g_verts, const float* v_posed, float* g_vposed,
-                         float* dA, int dA_stride, int B, hipStream_t st);
+                         float* dA, int dA_stride, float* scratch, int B, hipStream_t st);
 
 // ---- optional per-kernel timing (HIP events on the launch stream) -------------------------------------------
 // bench.py turns this on for its timed region: every kernel launch of the path is bracketed by an event pair on
@@ -121,7 +121,7 @@ extern "C" int saga_smplx_bwd(const saga_model_t* m, const float* g_vertices, co
     }
     if (has_verts) {
         SAGA_CHECK_ARG(ws_gvp && ws_slab, "saga_smplx_bwd: workspace missing");
-        { PROF(SAGA_PROF_SKIN_BWD); if ((rc = saga_launch_skin_bwd(m, A, gv, v_posed, ws_gvp, ws_dA, stride, B, st))) return rc; }
+        { PROF(SAGA_PROF_SKIN_BWD); if ((rc = saga_launch_skin_bwd(m, A, gv, v_posed, ws_gvp, ws_dA, stride, ws_slab, B, st))) return rc; }
         { PROF(SAGA_PROF_BLEND_BWD); if ((rc = saga_launch_blend_bwd(m, ws_gvp, ws_slab, B, st))) return rc; }
     }
     PROF(SAGA_PROF_POSE_BWD);
