@@ -99,7 +99,7 @@ int saga_smplx_fwd(const saga_model_t* m, const float* shape, const float* full_
  *   g_shape [B,S], g_full_pose [B,165], g_transl [B,3] : out
  * workspace (caller-allocated, contents undefined on entry):
  *   ws_gvp   [B,Npad]                 grad wrt v_posed
- *   ws_slab  [SAGA_BWD_SPLITK,B,512]  split-K partials of grad wrt feat
+ *   ws_slab  [SAGA_BWD_SPLITK,B,512]  split-K partials of grad wrt feat (before that: partial sums of ws_dA)
  *   ws_dA    [B,SAGA_DA_STRIDE]       grad wrt A ([56,12], row 55 = sum_v g) + compact joint grads
  *   ws_gv    [B,V,3] or NULL          required when g_joints is given (private copy of g_vertices
  *                                     that the extra-joint / landmark gradients are added into)
