@@ -479,7 +479,7 @@ __global__ void da_sum_kernel(const float* __restrict__ part, float* __restrict_
     dA[off] = acc;
 }
 
-// scratch: >= 9 * B * dA_stride floats, free for the duration of the call (the split-K slabs, written later), or NULL
+// scratch: >= 3 * B * dA_stride floats, free for the duration of the call (the split-K slabs, written later), or NULL
 int saga_launch_skin_bwd(const saga_model* m, const float* A, const float* g_verts, const float* v_posed, float* g_vposed,
                          float* dA, int dA_stride, float* scratch, int B, hipStream_t st) {
     const int per_block = SKIN_THREADS * SKIN_VPT;
@@ -488,12 +488,8 @@ int saga_launch_skin_bwd(const saga_model* m, const float* A, const float* g_ver
     // three vertex ranges per candidate group: 3 x (B/4) blocks of a third of the length fill the 3 blocks/CU evenly (B = 4096:
     // 3072 blocks = 4 full rounds instead of 1 1/3) and keep small batches from leaving the chip idle
     const int n_steps = (m->V + DA_STEP - 1) / DA_STEP;
-    int parts = 1;
-    if (scratch && n_steps >= 48) {
-        parts = 3;
-        if (blocks * parts < 768) parts = min((768 + blocks - 1) / blocks, 9);     // small batches: up to 9 ranges (scratch holds 9)
-        parts = max(1, min(parts, n_steps / 16));
-    }
+    // (a fixed number of ranges, whatever the batch: a candidate's sums must not depend on the batch around it)
+    const int parts = (scratch && n_steps >= 48) ? 3 : 1;
     const size_t part_stride = (size_t)B * dA_stride;
     float* out = parts > 1 ? scratch : dA;
     dim3 grid(blocks, parts);
