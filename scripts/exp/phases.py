@@ -1,3 +1,4 @@
+"""Phase timing of the fused loss kernel: needs a build of the library with -DGL_PHASE_TIMING loaded through SAGA_HIP_LIB."""
 import ctypes, os, sys, json, subprocess
 sys.path.insert(0, os.getcwd())
 import torch, tempfile
