@@ -18,7 +18,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (tile i: vertex base + i*256 + tid, so the 12-B per-lane accesses of a wave are one contiguous 768-B run) and issues
 // all of its loads before the barrier.  KW4: the compressed weight table has exactly 4 entries per vertex and is read
 // as one int4 + one float4.
+#ifndef SKIN_VPT
 #define SKIN_VPT 4
+#endif
 template <bool KW4>
 __global__ __launch_bounds__(SKIN_THREADS) void skin_fwd_kernel(const float* __restrict__ A, const float* __restrict__ v_posed,
                                                                 const int32_t* __restrict__ w_idx,
@@ -37,7 +39,8 @@ __global__ __launch_bounds__(SKIN_THREADS) void skin_fwd_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < SKIN_VPT; ++i) {
         const int v = min(vbase + i * SKIN_THREADS + tid, V - 1);
-        px[i] = src[v * 3]; py[i] = src[v * 3 + 1]; pz[i] = src[v * 3 + 2];
+        const float3 p3 = *reinterpret_cast<const float3*>(src + v * 3);       // one 12-B load (global_load_dwordx3)
+        px[i] = p3.x; py[i] = p3.y; pz[i] = p3.z;
         if (KW4) {
             ji[i] = reinterpret_cast<const int4*>(w_idx)[v];
             wv[i] = reinterpret_cast<const float4*>(w_val)[v];
@@ -74,9 +77,11 @@ __global__ __launch_bounds__(SKIN_THREADS) void skin_fwd_kernel(const float* __r
                 for (int q = 0; q < 12; ++q) T[q] = fmaf(w, a[q], T[q]);
             }
         }
-        dst[v * 3] = (T[0] * px[i] + T[1] * py[i] + T[2] * pz[i] + T[3]) + tx;
-        dst[v * 3 + 1] = (T[4] * px[i] + T[5] * py[i] + T[6] * pz[i] + T[7]) + ty;
-        dst[v * 3 + 2] = (T[8] * px[i] + T[9] * py[i] + T[10] * pz[i] + T[11]) + tz;
+        float3 o;
+        o.x = (T[0] * px[i] + T[1] * py[i] + T[2] * pz[i] + T[3]) + tx;
+        o.y = (T[4] * px[i] + T[5] * py[i] + T[6] * pz[i] + T[7]) + ty;
+        o.z = (T[8] * px[i] + T[9] * py[i] + T[10] * pz[i] + T[11]) + tz;
+        *reinterpret_cast<float3*>(dst + v * 3) = o;                             // one 12-B store
     }
 }
 
