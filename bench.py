@@ -35,7 +35,7 @@ V, K_ALG = 10475, 506       # algorithmic K of the blend contraction: 20 shape +
 PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'round1_pmc_summary.json')
 
 
-def stage_rooflines(prof, steps, B, n_obj):
+def stage_rooflines(prof, steps, B, n_obj, V=10475):
     """Per-kernel achieved rate against the roofline that bounds it (SURVEY.md 8d figures x B / live HIP-event time)."""
     ms = lambda k: prof[k][0] / max(prof[k][1], 1) if k in prof and prof[k][1] else None
     out = {}
@@ -80,17 +80,20 @@ def parse():
     ap.add_argument('--obj-points', type=int, default=2048)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--autograd', action='store_true', help='PyTorch autograd + torch.optim.Adam instead of saga_fit_step')
+    ap.add_argument('--loss-vertices-only', action='store_true',
+                    help='SEPARATELY REPORTED variant (SURVEY 8d, V_sel): the body model evaluates only the ~1,100 vertices the loss reads')
     ap.add_argument('--cpu-batch', type=int, default=16)
     ap.add_argument('--cpu-iters', type=int, default=64)
     return ap.parse_args()
 
 
-def build_problem(B, n_obj, rank, model_root, device):
+def build_problem(B, n_obj, rank, model_root, device, loss_vertices_only=False):
     from saga_amd.fitting import FittingOP
     from saga_amd.synthetic import make_candidate_params, make_grasp_targets, make_object_cloud
     from saga_amd.vposer import VPoserDecoder
     vp = VPoserDecoder(seed=0)
-    op = FittingOP({'batch_size': B, 'device': device, 'body_model_path': model_root, 'vposer': vp, 'genders': ('male',)})
+    op = FittingOP({'batch_size': B, 'device': device, 'body_model_path': model_root, 'vposer': vp, 'genders': ('male',),
+                    'loss_vertices_only': loss_vertices_only})
     op.bm = op.bm_male
     op.set_variables(make_candidate_params(B, seed=1234 + 7919 * rank, scale=0.3))
     vo, no, _, _ = make_object_cloud(B, n_points=n_obj, seed=rank)
@@ -160,7 +163,8 @@ def main():
     B, n_obj = args.batch, args.obj_points
     tmp = tempfile.TemporaryDirectory()
     write_body_model(tmp.name, gender='male', seed=7)
-    op, vp, d = build_problem(B, n_obj, rank, tmp.name, str(device))
+    op, vp, d = build_problem(B, n_obj, rank, tmp.name, str(device), args.loss_vertices_only)
+    V_eval = op.bm.num_verts
     optimizer = op.optimizer_s3 if args.autograd else None
 
     def barrier():
@@ -206,7 +210,7 @@ def main():
         # dominant kernel: the FP32-MFMA blend contraction (forward + backward launches are the same kernel template)
         gemm_ms = prof_gemm['blend_gemm_fwd'][0] + prof_gemm['blend_gemm_bwd'][0]      # live, inside the timed region
         gemm_n = prof_gemm['blend_gemm_fwd'][1] + prof_gemm['blend_gemm_bwd'][1]
-        flop_per_launch = 2.0 * B * (3 * V) * K_ALG            # algorithmic: [B,506] x [506,31425], fwd == bwd
+        flop_per_launch = 2.0 * B * (3 * V_eval) * K_ALG       # algorithmic: [B,506] x [506,31425], fwd == bwd
         achieved = flop_per_launch / (gemm_ms / max(gemm_n, 1) * 1e-3) / 1e12 if gemm_n else None
         kernels = {k: {'ms_per_step': round(ms / args.steps, 4), 'launches_per_step': n / args.steps}
                    for k, (ms, n) in prof.items() if n}
@@ -218,20 +222,22 @@ def main():
             'ms_per_step': round(ms_per_step, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'GraspPose-Opt stage-3 iteration: SMPL-X fwd+bwd (V=10475, full mesh) + hand normals + '
-                                   '2 bidirectional NN vs %d object points + contact/collision losses + Adam' % n_obj,
+            'config': {'workload': 'GraspPose-Opt stage-3 iteration: SMPL-X fwd+bwd (%s) + hand normals + '
+                                   '2 bidirectional NN vs %d object points + contact/collision losses + Adam'
+                                   % ('V=10475, full mesh' if not args.loss_vertices_only else
+                                      'VARIANT: only the %d loss vertices of 10475 are evaluated' % V_eval, n_obj),
                        'driver': 'torch autograd + torch.optim.Adam' if args.autograd else 'saga_fit_step (one kernel sequence)',
                        'candidates_per_gpu': B, 'candidates_total': B * world, 'object_points': n_obj,
                        'candidate_iterations_per_s': round(iters_per_s * B, 1),
                        'parallelism': 'candidates sharded, %d rank(s), no data-path collective' % world,
                        'best_of_8_mean_loss': float(best_loss.mean()), 'kernels': kernels,
-                       'stages': stage_rooflines(prof, args.steps, B, n_obj)},
+                       'stages': stage_rooflines(prof, args.steps, B, n_obj, V_eval)},
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_f32_kernel (blend contraction, fwd+bwd launches)',
                          'achieved': None if achieved is None else round(achieved, 2), 'peak': PEAK_F32_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': None if achieved is None else round(achieved / PEAK_F32_TFLOPS, 4),
-                         'traffic': pmc_traffic(),
+                         'traffic': None if args.loss_vertices_only else pmc_traffic(),
                          'traffic_note': 'HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/); '
-                                         'algorithmic bytes per launch = %d' % int(B * 3 * V * 4 + B * 512 * 4 + 3 * V * 512 * 4)},
+                                         'algorithmic bytes per launch = %d' % int(B * 3 * V_eval * 4 + B * 512 * 4 + 3 * V_eval * 512 * 4)},
         }
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only (host cores are shared by the ranks)
             cand_per_s, threads, dt = cpu_baseline(tmp.name, vp, n_obj, args.cpu_batch, args.cpu_iters)

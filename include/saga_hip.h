@@ -63,6 +63,14 @@ typedef struct {
 } saga_model_desc_t;
 
 int  saga_model_create(saga_model_t** out, const saga_model_desc_t* desc);
+/* The same model restricted to the listed vertices (ascending ids into the descriptor's arrays): every per-vertex table
+ * holds those vertices only (V = n_ids), the joint regression still runs over the full arrays, the faces kept are those
+ * with all three corners listed (renumbered, original order); n_landmarks and n_extra_joints must be 0.  A listed
+ * vertex gets bit-identical coordinates to the full model's.  For callers that read a few vertices only -- the fitting
+ * loss reads ~1,050 markers / hand / foot vertices of 10,475 (the "V_sel" variant); no
+ * counterpart in smplx, which always evaluates the whole mesh (fittingop.py:149). */
+int  saga_model_create_subset(saga_model_t** out, const saga_model_desc_t* desc, const int32_t* vertex_ids_host, int n_ids);
+int  saga_model_num_faces(const saga_model_t* m);
 void saga_model_destroy(saga_model_t* m);
 /* padded row length (floats) of v_posed / grad_v_posed buffers: roundup(3V, SAGA_N_ALIGN) */
 int  saga_model_npad(const saga_model_t* m);

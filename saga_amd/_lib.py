@@ -79,6 +79,8 @@ PROTOTYPES = {
     'saga_last_error': (ctypes.c_char_p, []),
     'saga_version': (ctypes.c_int, []),
     'saga_model_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ModelDesc)]),
+    'saga_model_create_subset': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_int]),
+    'saga_model_num_faces': (ctypes.c_int, [ctypes.c_void_p]),
     'saga_model_destroy': (None, [ctypes.c_void_p]),
     'saga_model_npad': (ctypes.c_int, [ctypes.c_void_p]),
     'saga_model_num_joints_out': (ctypes.c_int, [ctypes.c_void_p]),

@@ -41,11 +41,21 @@ extern "C" int saga_model_npad(const saga_model_t* m) { return m ? m->Npad : SAG
 extern "C" int saga_model_num_joints_out(const saga_model_t* m) { return m ? NJ + m->E + m->L : SAGA_EINVAL; }
 extern "C" int saga_model_weight_nnz(const saga_model_t* m) { return m ? m->KW : SAGA_EINVAL; }
 
-extern "C" int saga_model_create(saga_model_t** out, const saga_model_desc_t* d) {
+// sel (optional): ascending ids of the vertices the model keeps.  VF = vertices of the arrays in the descriptor, V = vertices of
+// the model; the joint regression always runs over the full arrays.
+static int model_create_impl(saga_model_t** out, const saga_model_desc_t* d, const int32_t* sel, int n_sel) {
     SAGA_CHECK_ARG(out && d, "saga_model_create: null argument");
     *out = nullptr;
-    const int V = d->n_verts, S = d->n_shape, F = d->n_faces, L = d->n_landmarks, E = d->n_extra_joints;
-    SAGA_CHECK_ARG(V > 0 && F >= 0 && L >= 0 && E >= 0, "saga_model_create: bad sizes V=%d F=%d L=%d E=%d", V, F, L, E);
+    const int VF = d->n_verts, S = d->n_shape, L = d->n_landmarks, E = d->n_extra_joints;
+    const int V = sel ? n_sel : VF;
+    int F = d->n_faces;
+    SAGA_CHECK_ARG(VF > 0 && V > 0 && F >= 0 && L >= 0 && E >= 0, "saga_model_create: bad sizes V=%d F=%d L=%d E=%d", VF, F, L, E);
+    if (sel) {
+        SAGA_CHECK_ARG(L == 0 && E == 0, "saga_model_create_subset: a vertex subset has no landmark / extra-joint outputs (pass L = E = 0)");
+        for (int i = 0; i < n_sel; ++i)
+            SAGA_CHECK_ARG(sel[i] >= 0 && sel[i] < VF && (i == 0 || sel[i] > sel[i - 1]), "saga_model_create_subset: ids must be ascending and < V");
+    }
+    auto sv = [&](int v) { return sel ? sel[v] : v; };
     SAGA_CHECK_ARG(S >= 0 && S + NPF <= FEAT_K, "saga_model_create: n_shape=%d does not fit K=%d", S, FEAT_K);
     SAGA_CHECK_ARG(d->v_template_host && d->posedirs_host && d->J_regressor_host && d->parents_host &&
                        d->lbs_weights_host && (S == 0 || d->shapedirs_host),
@@ -58,11 +68,11 @@ extern "C" int saga_model_create(saga_model_t** out, const saga_model_desc_t* d)
         SAGA_CHECK_ARG(d->parents_host[j] >= 0 && d->parents_host[j] < j, "saga_model_create: parents[%d]=%d not topological", j,
                        d->parents_host[j]);
     for (int f = 0; f < 3 * F; ++f)
-        SAGA_CHECK_ARG(d->faces_host[f] >= 0 && d->faces_host[f] < V, "saga_model_create: face index out of range");
+        SAGA_CHECK_ARG(d->faces_host[f] >= 0 && d->faces_host[f] < VF, "saga_model_create: face index out of range");
     for (int l = 0; l < L; ++l)
         SAGA_CHECK_ARG(d->lmk_faces_idx_host[l] >= 0 && d->lmk_faces_idx_host[l] < F, "saga_model_create: landmark face out of range");
     for (int e = 0; e < E; ++e)
-        SAGA_CHECK_ARG(d->extra_joint_verts_host[e] >= 0 && d->extra_joint_verts_host[e] < V,
+        SAGA_CHECK_ARG(d->extra_joint_verts_host[e] >= 0 && d->extra_joint_verts_host[e] < VF,
                        "saga_model_create: extra joint vertex %d out of range", d->extra_joint_verts_host[e]);
 
     hipDeviceProp_t prop;
@@ -76,7 +86,7 @@ extern "C" int saga_model_create(saga_model_t** out, const saga_model_desc_t* d)
 
     saga_model* m = new saga_model();
     memset(m, 0, sizeof(*m));
-    m->V = V; m->S = S; m->F = F; m->L = L; m->E = E;
+    m->V = V; m->S = S; m->L = L; m->E = E;       // m->F below (a subset keeps only the faces inside it)
     m->N = 3 * V;
     m->Npad = saga_roundup(3 * V, SAGA_N_ALIGN);
     m->Vpad4 = saga_roundup(V, 256);
@@ -88,9 +98,10 @@ extern "C" int saga_model_create(saga_model_t** out, const saga_model_desc_t* d)
         std::vector<float> Bt((size_t)Npad * FEAT_K, 0.f), Bk((size_t)FEAT_K * Npad, 0.f), vt(Npad, 0.f);
         for (int n = 0; n < N; ++n) {
             float* row = &Bt[(size_t)n * FEAT_K];
-            for (int s = 0; s < S; ++s) row[s] = d->shapedirs_host[(size_t)n * S + s];
-            for (int p = 0; p < NPF; ++p) row[S + p] = d->posedirs_host[(size_t)p * N + n];
-            vt[n] = d->v_template_host[n];
+            const size_t ns = (size_t)sv(n / 3) * 3 + n % 3;         // coordinate index in the descriptor's arrays
+            for (int s = 0; s < S; ++s) row[s] = d->shapedirs_host[ns * S + s];
+            for (int p = 0; p < NPF; ++p) row[S + p] = d->posedirs_host[(size_t)p * (3 * (size_t)VF) + ns];
+            vt[n] = d->v_template_host[ns];
         }
         for (int k = 0; k < FEAT_K; ++k)
             for (int n = 0; n < N; ++n) Bk[(size_t)k * Npad + n] = Bt[(size_t)n * FEAT_K + k];
@@ -99,10 +110,10 @@ extern "C" int saga_model_create(saga_model_t** out, const saga_model_desc_t* d)
     {   // folded joint regression (accumulated in double)
         std::vector<float> Jt(NJ * 3), Jd((size_t)std::max(S, 1) * NJ * 3, 0.f);
         for (int j = 0; j < NJ; ++j) {
-            const float* reg = d->J_regressor_host + (size_t)j * V;
+            const float* reg = d->J_regressor_host + (size_t)j * VF;
             double acc[3] = {0, 0, 0};
             std::vector<double> accd((size_t)3 * S, 0.0);
-            for (int v = 0; v < V; ++v) {
+            for (int v = 0; v < VF; ++v) {
                 double w = reg[v];
                 if (w == 0.0) continue;
                 for (int c = 0; c < 3; ++c) {
@@ -136,7 +147,7 @@ extern "C" int saga_model_create(saga_model_t** out, const saga_model_desc_t* d)
         int KW = 1;
         for (int v = 0; v < V; ++v) {
             int nnz = 0;
-            for (int j = 0; j < NJ; ++j) nnz += d->lbs_weights_host[(size_t)v * NJ + j] != 0.f;
+            for (int j = 0; j < NJ; ++j) nnz += d->lbs_weights_host[(size_t)sv(v) * NJ + j] != 0.f;
             KW = std::max(KW, nnz);
         }
         KW = saga_roundup(KW, 2);
@@ -146,7 +157,7 @@ extern "C" int saga_model_create(saga_model_t** out, const saga_model_desc_t* d)
         for (int v = 0; v < V; ++v) {
             int k = 0;
             for (int j = 0; j < NJ; ++j) {
-                float w = d->lbs_weights_host[(size_t)v * NJ + j];
+                float w = d->lbs_weights_host[(size_t)sv(v) * NJ + j];
                 Wd[(size_t)v * WT_COLS + (j & 15) * 4 + (j >> 4)] = w;      // column j at slot (j%16)*4 + j/16
                 if (w != 0.f) { wi[(size_t)v * KW + k] = j; wv[(size_t)v * KW + k] = w; ++k; }
             }
@@ -155,7 +166,19 @@ extern "C" int saga_model_create(saga_model_t** out, const saga_model_desc_t* d)
         if ((rc = upload(&m->w_idx, wi)) || (rc = upload(&m->w_val, wv)) || (rc = upload(&m->Wd, Wd))) goto fail;
     }
     {   // faces, vertex->face incidence (ascending face order), landmarks, extra joints
-        std::vector<int32_t> faces(d->faces_host, d->faces_host + (size_t)3 * F), vptr(V + 1, 0), vidx((size_t)3 * F);
+        std::vector<int32_t> faces(d->faces_host, d->faces_host + (size_t)3 * F);
+        if (sel) {      // keep the faces whose three corners are kept, in their order, with the corners renumbered
+            std::vector<int32_t> pos(VF, -1), kept;
+            for (int i = 0; i < n_sel; ++i) pos[sel[i]] = i;
+            for (int f = 0; f < F; ++f) {
+                const int a = pos[faces[f * 3]], b = pos[faces[f * 3 + 1]], c = pos[faces[f * 3 + 2]];
+                if (a >= 0 && b >= 0 && c >= 0) { kept.push_back(a); kept.push_back(b); kept.push_back(c); }
+            }
+            faces.swap(kept);
+            F = (int)(faces.size() / 3);
+        }
+        m->F = F;
+        std::vector<int32_t> vptr(V + 1, 0), vidx((size_t)3 * F);
         for (int f = 0; f < 3 * F; ++f) vptr[faces[f] + 1]++;
         for (int v = 0; v < V; ++v) vptr[v + 1] += vptr[v];
         std::vector<int32_t> fill(vptr.begin(), vptr.end() - 1);
@@ -180,3 +203,12 @@ fail:
     saga_model_destroy(m);
     return rc;
 }
+
+extern "C" int saga_model_create(saga_model_t** out, const saga_model_desc_t* d) { return model_create_impl(out, d, nullptr, 0); }
+
+extern "C" int saga_model_create_subset(saga_model_t** out, const saga_model_desc_t* d, const int32_t* vertex_ids_host, int n_ids) {
+    SAGA_CHECK_ARG(vertex_ids_host && n_ids > 0, "saga_model_create_subset: empty vertex list");
+    return model_create_impl(out, d, vertex_ids_host, n_ids);
+}
+
+extern "C" int saga_model_num_faces(const saga_model_t* m) { return m ? m->F : SAGA_EINVAL; }

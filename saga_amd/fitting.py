@@ -43,6 +43,17 @@ def load_grasp_indices(path=None):
     return {k: d[k] for k in ('markers_143', 'markers_f0_p5', 'rhand', 'lhand', 'foot', 'rhand_weight', 'foot_sizes')}
 
 
+def loss_vertex_subset(faces, idx):
+    """Ascending ids of the vertices one fitting iteration reads: the 143 markers, the right hand, the feet, and every corner
+    of a face that touches a right-hand vertex (the hand's vertex normals sum over its incident faces)."""
+    faces = np.asarray(faces)
+    hand = np.zeros(int(faces.max()) + 1 if faces.size else 0, dtype=bool)
+    rh = np.asarray(idx['rhand'])
+    hand[rh[rh < hand.shape[0]]] = True
+    ring = faces[hand[faces].any(axis=1)].reshape(-1) if faces.size else np.zeros(0, dtype=np.int64)
+    return np.unique(np.concatenate([np.asarray(idx['markers_143']), rh, np.asarray(idx['foot']), ring]).astype(np.int64))
+
+
 class FittingOP:
     """Same constructor contract as the reference (``FittingOP(fittingconfig)``, keys as at
     ``opt_grasppose.py:179-191``) plus optional keys: ``body_model_path`` (default
@@ -58,7 +69,7 @@ class FittingOP:
                    verbose=False, hand_ncomps=24, only_rec=False, contact_loss='contact', logger=print,
                    data_type='markers_143', body_model_path='./body_utils/body_models', vposer=None, indices=None,
                    smplx_kwargs={}, genders=('male', 'female'), fused=True, native=True,
-                   record_history=True)
+                   record_history=True, loss_vertices_only=False)
         cfg.update(fittingconfig)
         for key, val in cfg.items():
             setattr(self, key, val)
@@ -66,14 +77,22 @@ class FittingOP:
         if self.device.type != 'cuda':
             raise RuntimeError('saga_amd.FittingOP runs on a ROCm GPU only (device=%s)' % self.device)
         B = self.batch_size
+        idx = dict(self.indices if self.indices is not None else load_grasp_indices())
+        subset = [None]
 
         def make(gender):
-            bm = _smplx.create(self.body_model_path, model_type='smplx', gender=gender, ext='npz',
-                               num_pca_comps=self.hand_ncomps, create_global_orient=True, create_body_pose=True,
-                               create_betas=True, create_left_hand_pose=True, create_right_hand_pose=True,
-                               create_expression=True, create_jaw_pose=True, create_leye_pose=True,
-                               create_reye_pose=True, create_transl=True, batch_size=B, **self.smplx_kwargs)
-            return bm.to(self.device).eval()
+            kw = dict(model_type='smplx', gender=gender, ext='npz', num_pca_comps=self.hand_ncomps, create_global_orient=True,
+                      create_body_pose=True, create_betas=True, create_left_hand_pose=True, create_right_hand_pose=True,
+                      create_expression=True, create_jaw_pose=True, create_leye_pose=True, create_reye_pose=True,
+                      create_transl=True, batch_size=B, **self.smplx_kwargs)
+            if self.loss_vertices_only:
+                # the full module is only read for its faces (no device model is created for it)
+                sub = loss_vertex_subset(_smplx.create(self.body_model_path, **kw).faces, idx)
+                if subset[0] is not None and not np.array_equal(subset[0], sub):
+                    raise ValueError('the body models of the two genders have different faces around the loss vertices')
+                subset[0] = sub
+                kw['vertex_subset'] = sub
+            return _smplx.create(self.body_model_path, **kw).to(self.device).eval()
 
         self.bm_male = make('male') if 'male' in self.genders else None
         self.bm_female = make('female') if 'female' in self.genders else None
@@ -101,7 +120,10 @@ class FittingOP:
         self._decoder = None
         self._ws = None
 
-        idx = self.indices if self.indices is not None else load_grasp_indices()
+        if subset[0] is not None:          # vertex ids -> positions in the subset the model evaluates
+            for k in ('markers_143', 'rhand', 'foot'):
+                idx[k] = np.searchsorted(subset[0], np.asarray(idx[k]))
+        self.vertex_subset = subset[0]
         dev = self.device
         self.v_weights = torch.as_tensor(np.asarray(idx['rhand_weight']), dtype=torch.float32, device=dev)
         self.v_weights2 = torch.pow(self.v_weights, 1.0 / 2.5)

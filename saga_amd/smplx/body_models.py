@@ -52,7 +52,7 @@ class SMPLX(nn.Module):
                  create_global_orient=True, create_body_pose=True, create_betas=True,
                  create_left_hand_pose=True, create_right_hand_pose=True, create_expression=True,
                  create_jaw_pose=True, create_leye_pose=True, create_reye_pose=True, create_transl=True,
-                 v_template=None, vertex_ids=None, use_face_contour=False, dtype=torch.float32, **kwargs):
+                 v_template=None, vertex_ids=None, use_face_contour=False, dtype=torch.float32, vertex_subset=None, **kwargs):
         super().__init__()
         if dtype != torch.float32:
             raise TypeError('saga_amd.smplx computes in float32 only')
@@ -111,6 +111,23 @@ class SMPLX(nn.Module):
             'lmk_faces_idx': i32(data['lmk_faces_idx']), 'lmk_bary': c32(data['lmk_bary_coords']),
             'extra': extra,
         }
+        # vertex_subset (not in smplx): evaluate the listed vertices only (ascending ids).  ``vertices`` is then [B, n, 3] in
+        # list order, bit-identical to the same rows of the full mesh; ``faces`` are the faces inside the subset, renumbered;
+        # ``joints`` are the 55 skeleton joints only (picked-vertex joints and landmarks need the whole mesh).
+        self.vertex_subset = None
+        if vertex_subset is not None:
+            sub = np.unique(np.asarray(vertex_subset, dtype=np.int64))
+            if sub.size == 0 or sub[0] < 0 or sub[-1] >= V:
+                raise ValueError('vertex_subset ids must lie in [0, %d)' % V)
+            self.vertex_subset = i32(sub)
+            pos = np.full(V, -1, dtype=np.int64)
+            pos[sub] = np.arange(sub.size)
+            keep = (pos[faces] >= 0).all(axis=1)
+            faces = pos[faces[keep]]
+            self._host['lmk_faces_idx'] = i32(np.zeros(0))
+            self._host['lmk_bary'] = c32(np.zeros((0, 3)))
+            self._host['extra'] = extra = np.zeros(0, dtype=np.int32)
+            self.num_verts_full, V, vt = V, int(sub.size), vt[sub]
         self.num_verts = V
         self.num_shape = num_betas + num_expression_coeffs
         self.num_joints_out = NUM_JOINTS + len(extra) + self._host['lmk_faces_idx'].shape[0]
@@ -158,7 +175,7 @@ class SMPLX(nn.Module):
             hp = self._host
             p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
             desc = _lib.ModelDesc(
-                n_verts=self.num_verts, n_shape=self.num_shape, n_faces=hp['faces'].shape[0],
+                n_verts=hp['v_template'].shape[0], n_shape=self.num_shape, n_faces=hp['faces'].shape[0],
                 n_landmarks=hp['lmk_faces_idx'].shape[0], n_extra_joints=hp['extra'].shape[0],
                 v_template_host=p(hp['v_template']), shapedirs_host=p(hp['shapedirs']), posedirs_host=p(hp['posedirs']),
                 J_regressor_host=p(hp['J_regressor']), parents_host=p(hp['parents']), lbs_weights_host=p(hp['weights']),
@@ -166,7 +183,11 @@ class SMPLX(nn.Module):
                 extra_joint_verts_host=p(hp['extra']))
             out = ctypes.c_void_p()
             with torch.cuda.device(idx):
-                _lib.check(lib.saga_model_create(ctypes.byref(out), ctypes.byref(desc)), 'saga_model_create')
+                if self.vertex_subset is None:
+                    _lib.check(lib.saga_model_create(ctypes.byref(out), ctypes.byref(desc)), 'saga_model_create')
+                else:
+                    _lib.check(lib.saga_model_create_subset(ctypes.byref(out), ctypes.byref(desc), p(self.vertex_subset),
+                                                            int(self.vertex_subset.shape[0])), 'saga_model_create_subset')
             h = out
             self._handles[idx] = h
         return h

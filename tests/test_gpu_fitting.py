@@ -211,3 +211,50 @@ def test_workspace_reuse_across_problems_is_clean(body_model_dir):
     assert torch.equal(la, lb) and torch.equal(ma, mb) and torch.equal(op_a.vars, op_b.vars)
     assert torch.equal(op_a.workspace_view('g_vertices', 2048, (B, op_a.bm.num_verts, 3)),
                        op_b.workspace_view('g_vertices', 2048, (B, op_b.bm.num_verts, 3)))
+
+
+def wip_test_loss_vertices_only_variant_equals_full_mesh(body_model_dir):
+    """`loss_vertices_only=True` builds the body model for the ~1,100 vertices the loss reads (saga_model_create_subset).
+    The kept vertices are bit-identical to the full mesh's, so the first iteration's loss terms, counts and fitted markers
+    are EQUAL; the gradient sums run over fewer (all non-zero) vertices, so later iterations agree to rounding."""
+    from saga_amd.fitting import FittingOP
+    from saga_amd.vposer import VPoserDecoder
+    B = 5
+    _, _, _, var_np, data = _setup(body_model_dir, B)
+    vp = VPoserDecoder(seed=0)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    res = {}
+    for sub in (False, True):
+        op = FittingOP({'batch_size': B, 'device': 'cuda', 'body_model_path': body_model_dir, 'vposer': vp, 'genders': ('male',),
+                        'loss_vertices_only': sub})
+        op.bm = op.bm_male
+        op.set_variables(var_np)
+        prob = op.make_problem(cu(data['markers']), cu(data['verts_o']), cu(data['normals_o']), cu(data['oc']), cu(data['mc']))
+        terms = torch.zeros(B, 16, device='cuda')
+        hist = []
+        for _ in range(4):
+            loss, mk = op.native_step(2, prob, terms)
+            hist.append((loss.clone(), mk.clone(), terms.clone()))
+        res[sub] = (op, hist, op.vars.clone())
+    full, part = res[False], res[True]
+    # (the synthetic model's faces are random triangles, so the ring of faces around the hand drags in thousands of vertices;
+    #  a real mesh adds a thin band at the wrist)
+    assert part[0].bm.num_verts < 0.7 * full[0].bm.num_verts and part[0].vertex_subset is not None
+    assert torch.equal(full[1][0][0], part[1][0][0]) and torch.equal(full[1][0][1], part[1][0][1]) and torch.equal(full[1][0][2], part[1][0][2])
+    for (lf, mf, _), (lp, mp, _) in zip(full[1][1:], part[1][1:]):
+        np.testing.assert_allclose(lp.cpu().numpy(), lf.cpu().numpy(), rtol=LOSS_RTOL)
+        np.testing.assert_allclose(mp.cpu().numpy(), mf.cpu().numpy(), atol=1e-5)
+    np.testing.assert_allclose(part[2].cpu().numpy(), full[2].cpu().numpy(), atol=2e-5)
+    # the drop-in module with a subset: rows of the full mesh, bit for bit
+    import saga_amd.smplx as smplx
+    ids = part[0].vertex_subset
+    kw = dict(model_type='smplx', gender='male', ext='npz', num_pca_comps=24, batch_size=B)
+    bm_f = smplx.create(body_model_dir, **kw).cuda()
+    bm_s = smplx.create(body_model_dir, vertex_subset=ids, **kw).cuda()
+    g = torch.Generator().manual_seed(3)
+    args = dict(betas=torch.randn(B, 10, generator=g).cuda(), body_pose=0.3 * torch.randn(B, 63, generator=g).cuda(),
+                global_orient=torch.randn(B, 3, generator=g).cuda(), transl=torch.randn(B, 3, generator=g).cuda())
+    with torch.no_grad():
+        vf, vs = bm_f(**args).vertices, bm_s(**args)
+    assert vs.vertices.shape == (B, len(ids), 3) and torch.equal(vf[:, torch.from_numpy(ids).long().cuda()], vs.vertices)
+    assert vs.joints.shape == (B, 55, 3) and bm_s.faces.max() < len(ids)
