@@ -82,6 +82,8 @@ def parse():
     ap.add_argument('--autograd', action='store_true', help='PyTorch autograd + torch.optim.Adam instead of saga_fit_step')
     ap.add_argument('--loss-vertices-only', action='store_true',
                     help='SEPARATELY REPORTED variant (SURVEY 8d, V_sel): the body model evaluates only the ~1,100 vertices the loss reads')
+    ap.add_argument('--local-weights', action='store_true',
+                    help='synthetic skinning weights with mesh-like locality (runs of vertices share their joints); reported separately')
     ap.add_argument('--cpu-batch', type=int, default=16)
     ap.add_argument('--cpu-iters', type=int, default=64)
     return ap.parse_args()
@@ -162,7 +164,7 @@ def main():
 
     B, n_obj = args.batch, args.obj_points
     tmp = tempfile.TemporaryDirectory()
-    write_body_model(tmp.name, gender='male', seed=7)
+    write_body_model(tmp.name, gender='male', seed=7, local_weights=args.local_weights)
     op, vp, d = build_problem(B, n_obj, rank, tmp.name, str(device), args.loss_vertices_only)
     V_eval = op.bm.num_verts
     optimizer = op.optimizer_s3 if args.autograd else None
@@ -226,6 +228,8 @@ def main():
                                    '2 bidirectional NN vs %d object points + contact/collision losses + Adam'
                                    % ('V=10475, full mesh' if not args.loss_vertices_only else
                                       'VARIANT: only the %d loss vertices of 10475 are evaluated' % V_eval, n_obj),
+                       'skinning_weights': ('VARIANT: 4 non-zeros per vertex, runs of vertices share their joints (mesh-like)' if args.local_weights
+                                            else '4 non-zeros per vertex at random joints (SURVEY 8d synthetic model)'),
                        'driver': 'torch autograd + torch.optim.Adam' if args.autograd else 'saga_fit_step (one kernel sequence)',
                        'candidates_per_gpu': B, 'candidates_total': B * world, 'object_points': n_obj,
                        'candidate_iterations_per_s': round(iters_per_s * B, 1),

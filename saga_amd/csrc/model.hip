@@ -30,7 +30,7 @@ static int upload(T** dst, const std::vector<T>& src) {
 extern "C" void saga_model_destroy(saga_model_t* m) {
     if (!m) return;
     void* ptrs[] = {m->Bt, m->Bk, m->v_template, m->J_template, m->J_dirs, m->parents, m->depth, m->child_ptr,
-                    m->child_idx, m->w_idx, m->w_val, m->Wd, m->faces, m->vf_ptr, m->vf_idx, m->vf_tri, m->lmk_verts,
+                    m->child_idx, m->w_idx, m->w_val, m->Wd, m->ds_ent, m->ds_meta, m->ds_item_ptr, m->faces, m->vf_ptr, m->vf_idx, m->vf_tri, m->lmk_verts,
                     m->lmk_bary, m->extra_verts};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -164,6 +164,44 @@ static int model_create_impl(saga_model_t** out, const saga_model_desc_t* d, con
             Wd[(size_t)v * WT_COLS + (NJ & 15) * 4 + (NJ >> 4)] = 1.f;
         }
         if ((rc = upload(&m->w_idx, wi)) || (rc = upload(&m->w_val, wv)) || (rc = upload(&m->Wd, Wd))) goto fail;
+    }
+    {   // sparse dA reduction tables (see saga_common.h)
+        const int P = (V + DS_VR - 1) / DS_VR;
+        const int Vr = saga_roundup((V + P - 1) / P, 64);
+        std::vector<int2> ent;
+        std::vector<int32_t> meta, iptr;
+        bool ok = P <= DS_MAX_PARTS && (P - 1) * Vr < V && Vr <= DS_VR;
+        for (int r = 0; r < P && ok; ++r) {
+            const int lo = r * Vr, hi = std::min(V, lo + Vr);
+            std::vector<std::vector<int2>> lists(NJ);
+            for (int v = lo; v < hi; ++v)
+                for (int j = 0; j < NJ; ++j) {
+                    const float w = d->lbs_weights_host[(size_t)sv(v) * NJ + j];
+                    if (w != 0.f) { int2 e; e.x = v - lo; memcpy(&e.y, &w, 4); lists[j].push_back(e); }
+                }
+            int C = 4;
+            auto n_items = [&](int c) { int n = 0; for (int j = 0; j < NJ; ++j) n += ((int)lists[j].size() + c - 1) / c; return n; };
+            while (C <= DS_MAX_CHUNK && n_items(C) > DS_THREADS) C += 4;
+            if (C > DS_MAX_CHUNK) { ok = false; break; }
+            const size_t off = ent.size();
+            meta.push_back((int32_t)off); meta.push_back(C);
+            int2 zero; zero.x = 0; zero.y = 0;
+            ent.resize(off + (size_t)C * DS_THREADS, zero);
+            int item = 0;
+            for (int j = 0; j < NJ; ++j) {
+                iptr.push_back(item);
+                // entry e of the joint goes to its item e % n, slot e / n: at every step the lanes of a joint read consecutive
+                // list entries (consecutive vertices when a body part's vertices are numbered together -> no LDS bank conflicts)
+                const size_t n = (lists[j].size() + C - 1) / C;
+                for (size_t e = 0; e < lists[j].size(); ++e) ent[off + (e / n) * DS_THREADS + item + e % n] = lists[j][e];
+                item += (int)n;
+            }
+            iptr.push_back(item);
+        }
+        if (ok) {
+            m->ds_parts = P; m->ds_vr = Vr;
+            if ((rc = upload(&m->ds_ent, ent)) || (rc = upload(&m->ds_meta, meta)) || (rc = upload(&m->ds_item_ptr, iptr))) goto fail;
+        }
     }
     {   // faces, vertex->face incidence (ascending face order), landmarks, extra joints
         std::vector<int32_t> faces(d->faces_host, d->faces_host + (size_t)3 * F);

@@ -11,6 +11,10 @@
 #define NPF 486                 // pose-feature length (54 joints x 9)
 #define FEAT_K SAGA_FEAT_K      // 512
 #define DA_ROWS 56              // 55 joints + 1 all-ones row (sum of gradients -> d transl)
+#define DS_THREADS 256          // sparse dA reduction: lanes (= items) per block
+#define DS_VR 1024              // ... and the most vertices a block stages in LDS (6 floats each: 42 KB)
+#define DS_MAX_PARTS 16         // partial sums live in the split-K slab space: parts * SAGA_DA_STRIDE <= 16 * 512 floats per candidate
+#define DS_MAX_CHUNK 64         // longer chunks mean the weights are dense: the MFMA reduction takes over
 #define WT_COLS 64              // dense weight table padded to 64 columns for the MFMA dA reduction
 
 void saga_set_error(const char* fmt, ...);
@@ -68,6 +72,13 @@ struct saga_model {
     float*   Wd;        // [Vpad4, 64]  column j of W (j<55; j=55: all ones; j>55: 0) sits at slot (j%16)*4 + j/16, so the
                         // four N-tile values of an MFMA lane (joints i16, i16+16, i16+32, i16+48) are one 16-B load; rows >= V are 0
     int Vpad4;          // roundup(V, 256)
+    // sparse dA reduction (skin.hip, skin_bwd_sparse_kernel): the vertices are cut into ds_parts ranges of ds_vr; per range the
+    // non-zero weights are listed joint by joint (ascending vertex), each joint's list cut into chunks of at most C entries
+    // so that a range has at most DS_THREADS chunks ("items", one per lane).  ds_parts = 0: table not built (weights too dense).
+    int ds_parts, ds_vr;
+    int2*    ds_ent;      // per range: [C][DS_THREADS] (vertex - range start, weight bits); pad entries have weight 0
+    int32_t* ds_meta;     // [ds_parts][2]: offset of the range's entries in ds_ent, C
+    int32_t* ds_item_ptr; // [ds_parts][NJ+1]: first item of each joint
     // faces / landmarks / extra joints
     int32_t* faces;     // [F,3]
     int32_t* vf_ptr;    // [V+1] CSR vertex -> incident (face, corner) in ascending face order

@@ -6,6 +6,8 @@
 // LBS weights come from a compressed (joint, weight) table (model constant, L2-resident), v_posed is read
 // and vertices are written exactly once.  The backward reduction dA[b,j] = sum_v W[v,j] g[b,v] (x) [v_posed;1]
 // is shaped as a GEMM over the vertex index and runs on v_mfma_f32_16x16x4_f32 (exact f32, deterministic).
+#include <stdlib.h>
+
 #include "saga_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -443,6 +445,201 @@ __global__ __launch_bounds__(256) void skin_bwd_dA_kernel(const float* __restric
     }
 }
 
+
+// ---- backward of skinning in one streaming pass, sparse weights ------------------------------------------------------
+// The skinning weights have a handful of non-zeros per vertex (4 in SMPL-family models), so the dense GEMM view above multiplies
+// mostly zeros (13.8 MFLOP per candidate against 1 MFLOP of useful work).  Here a block owns one candidate x one vertex range:
+//  phase 1  streams the range's g_vertices / v_posed rows once (coalesced 12-B accesses), writes g_v_posed = T^T g, and leaves
+//           (g, v_posed) in LDS (6 floats per vertex);
+//  phase 2  one lane per item (= a chunk of one joint's (vertex, weight) list inside the range, model constant, built by
+//           saga_model_create): the lane walks its chunk in ascending vertex order and accumulates its 12 sums in registers --
+//           no atomics, no cross-lane traffic;
+//  phase 3  the items of a joint are added in item order.  Every order is fixed: results are bit-reproducible and do not
+//           depend on the batch.  Partial sums per range go to slab blockIdx.y; da_sum_kernel adds the slabs in order.
+// Row 55 (sum_v g -> d transl): per-lane sums in vertex order, wave tree, waves in order.
+#define DS_VPT ((DS_VR + DS_THREADS - 1) / DS_THREADS)
+#define DS_OPT ((DA_ROWS * 12 + DS_THREADS - 1) / DS_THREADS)        // outputs per thread
+// A block walks `rpb` consecutive ranges of its candidate (grid.y blocks per candidate; each writes its own slab).  The next
+// range's rows are requested as soon as phase 1 has consumed the current ones, so they are in flight during phases 2 and 3.
+template <bool KW4>
+__global__ __launch_bounds__(DS_THREADS, 4) void skin_bwd_sparse_kernel(
+    const float* __restrict__ g_verts, const float* __restrict__ v_posed, const float* __restrict__ A,
+    const int32_t* __restrict__ w_idx, const float* __restrict__ w_val, const int2* __restrict__ ds_ent,
+    const int32_t* __restrict__ ds_meta, const int32_t* __restrict__ ds_item_ptr, float* __restrict__ g_vposed,
+    float* __restrict__ dA_part, int V, int Npad, int KW, int Vr, int n_ranges, int rpb, int dA_stride, size_t part_stride) {
+    __shared__ __attribute__((aligned(16))) float sX[DS_VR * 6];     // phase 1/2: [vertex][g.xyz, p.xyz]; phase 3: [12][DS_THREADS]
+    __shared__ __attribute__((aligned(16))) float sA[NJ * 12];
+    __shared__ float sG[DS_THREADS / 64][4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int r_begin = blockIdx.y * rpb, r_end = min(n_ranges, r_begin + rpb);
+    for (int i = tid; i < NJ * 12; i += DS_THREADS) sA[i] = A[(size_t)b * (NJ * 12) + i];
+    const float* gsrc = g_verts + (size_t)b * V * 3;
+    const float* psrc = v_posed + (size_t)b * Npad;
+    float* dst = g_vposed + (size_t)b * Npad;
+    float3 g[DS_VPT], p[DS_VPT];
+    int4 ji[DS_VPT];
+    float4 wv[DS_VPT];
+    int2 en[4];
+    auto fetch_rows = [&](int r) {
+        const int v_lo = r * Vr, n_here = min(Vr, V - v_lo);
+#pragma unroll
+        for (int i = 0; i < DS_VPT; ++i) {
+            const int v = v_lo + min(i * DS_THREADS + tid, n_here - 1);
+            g[i] = *reinterpret_cast<const float3*>(gsrc + (size_t)v * 3);
+            p[i] = *reinterpret_cast<const float3*>(psrc + (size_t)v * 3);
+        }
+    };
+    auto fetch_weights = [&](int r) {       // model constants (L2-resident): fetched when phase 1 starts, not a range ahead
+        const int v_lo = r * Vr, n_here = min(Vr, V - v_lo);
+#pragma unroll
+        for (int i = 0; i < DS_VPT; ++i) {
+            const int v = v_lo + min(i * DS_THREADS + tid, n_here - 1);
+            if (KW4) {
+                ji[i] = reinterpret_cast<const int4*>(w_idx)[v];
+                wv[i] = reinterpret_cast<const float4*>(w_val)[v];
+            }
+        }
+    };
+    auto fetch_first_entries = [&](int r) {
+        const int2* e = ds_ent + ds_meta[2 * r] + tid;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) en[u] = e[(size_t)u * DS_THREADS];
+    };
+    fetch_first_entries(r_begin);
+    fetch_rows(r_begin);
+    // pad columns [3V, Npad) of g_v_posed (the split-K GEMM reads them)
+    if (blockIdx.y == gridDim.y - 1)
+        for (int c = 3 * V + tid; c < Npad; c += DS_THREADS) dst[c] = 0.f;
+    float sgx = 0.f, sgy = 0.f, sgz = 0.f;
+    float outv[DS_OPT];
+#pragma unroll
+    for (int q = 0; q < DS_OPT; ++q) outv[q] = 0.f;
+
+    for (int r = r_begin; r < r_end; ++r) {
+        const int v_lo = r * Vr, n_here = min(Vr, V - v_lo);
+        fetch_weights(r);
+        __syncthreads();        // sA staged (first range) / phase 3 of the previous range has left sX
+#pragma unroll
+        for (int i = 0; i < DS_VPT; ++i) {
+            const int vl = i * DS_THREADS + tid;
+            if (vl >= n_here) continue;
+            const int v = v_lo + vl;
+            float T[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) T[k] = 0.f;
+            if (KW4) {
+                const int jj[4] = {ji[i].x, ji[i].y, ji[i].z, ji[i].w};
+                const float ww[4] = {wv[i].x, wv[i].y, wv[i].z, wv[i].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4* a = reinterpret_cast<const float4*>(sA + jj[k] * 12);
+                    const float4 a0 = a[0], a1 = a[1], a2 = a[2];
+                    const float w = ww[k];
+                    T[0] = fmaf(w, a0.x, T[0]); T[1] = fmaf(w, a0.y, T[1]); T[2] = fmaf(w, a0.z, T[2]);
+                    T[3] = fmaf(w, a1.x, T[3]); T[4] = fmaf(w, a1.y, T[4]); T[5] = fmaf(w, a1.z, T[5]);
+                    T[6] = fmaf(w, a2.x, T[6]); T[7] = fmaf(w, a2.y, T[7]); T[8] = fmaf(w, a2.z, T[8]);
+                }
+            } else {
+                for (int k = 0; k < KW; ++k) {
+                    const float w = w_val[(size_t)v * KW + k];
+                    if (w == 0.f) continue;
+                    const float* a = sA + w_idx[(size_t)v * KW + k] * 12;
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) T[rr * 3 + c] = fmaf(w, a[rr * 4 + c], T[rr * 3 + c]);
+                }
+            }
+            float3 o;
+            o.x = T[0] * g[i].x + T[3] * g[i].y + T[6] * g[i].z;
+            o.y = T[1] * g[i].x + T[4] * g[i].y + T[7] * g[i].z;
+            o.z = T[2] * g[i].x + T[5] * g[i].y + T[8] * g[i].z;
+            *reinterpret_cast<float3*>(dst + (size_t)v * 3) = o;
+            float2* row = reinterpret_cast<float2*>(sX + vl * 6);
+            row[0] = make_float2(g[i].x, g[i].y);
+            row[1] = make_float2(g[i].z, p[i].x);
+            row[2] = make_float2(p[i].y, p[i].z);
+            sgx += g[i].x; sgy += g[i].y; sgz += g[i].z;
+            __builtin_amdgcn_sched_barrier(0);      // one vertex at a time: interleaving them costs 40+ registers
+        }
+        const int C = ds_meta[2 * r + 1];
+        const int2* e = ds_ent + ds_meta[2 * r] + tid;
+        const int rn = min(r + 1, r_end - 1);
+        if (r + 1 < r_end) fetch_rows(rn);
+        __syncthreads();
+
+        // phase 2 (the lane's first entries were requested a range ago; each batch of 4 is requested one batch ahead)
+        float acc[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+        for (int c = 0; c < C; c += 4) {
+            int2 cur[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cur[u] = en[u];
+            const int cn = min(c + 4, C - 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) en[u] = e[(size_t)(cn + u) * DS_THREADS];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float2* row = reinterpret_cast<const float2*>(sX + cur[u].x * 6);
+                const float2 r0 = row[0], r1 = row[1], r2 = row[2];
+                const float w = __int_as_float(cur[u].y);
+                const float wg0 = w * r0.x, wg1 = w * r0.y, wg2 = w * r1.x;
+                const float px = r1.y, py = r2.x, pz = r2.y;
+                acc[0] = fmaf(wg0, px, acc[0]); acc[1] = fmaf(wg0, py, acc[1]); acc[2] = fmaf(wg0, pz, acc[2]); acc[3] += wg0;
+                acc[4] = fmaf(wg1, px, acc[4]); acc[5] = fmaf(wg1, py, acc[5]); acc[6] = fmaf(wg1, pz, acc[6]); acc[7] += wg1;
+                acc[8] = fmaf(wg2, px, acc[8]); acc[9] = fmaf(wg2, py, acc[9]); acc[10] = fmaf(wg2, pz, acc[10]); acc[11] += wg2;
+            }
+        }
+        fetch_first_entries(rn);
+        __syncthreads();        // every lane has left sX
+        float* sP = sX;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) sP[k * DS_THREADS + tid] = acc[k];
+        __syncthreads();
+        // phase 3: this thread's outputs += the items of their joint, in item order
+        const int32_t* iptr = ds_item_ptr + r * (NJ + 1);
+#pragma unroll
+        for (int q = 0; q < DS_OPT; ++q) {
+            const int o = q * DS_THREADS + tid;
+            const int j = o / 12, k = o - j * 12;
+            if (j < NJ) {
+                const int i0 = iptr[j], i1 = iptr[j + 1];
+                float s = outv[q];
+                int it = i0;
+                for (; it + 4 <= i1; it += 4) {     // loads issued together, added in item order
+                    const float a0 = sP[k * DS_THREADS + it], a1 = sP[k * DS_THREADS + it + 1], a2 = sP[k * DS_THREADS + it + 2],
+                                a3 = sP[k * DS_THREADS + it + 3];
+                    s += a0; s += a1; s += a2; s += a3;
+                }
+                for (; it < i1; ++it) s += sP[k * DS_THREADS + it];
+                outv[q] = s;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sgx += __shfl_down(sgx, o, 64); sgy += __shfl_down(sgy, o, 64); sgz += __shfl_down(sgz, o, 64);
+    }
+    if ((tid & 63) == 0) { sG[tid >> 6][0] = sgx; sG[tid >> 6][1] = sgy; sG[tid >> 6][2] = sgz; }
+    __syncthreads();
+    float* out = dA_part + (size_t)blockIdx.y * part_stride + (size_t)b * dA_stride;
+#pragma unroll
+    for (int q = 0; q < DS_OPT; ++q) {
+        const int o = q * DS_THREADS + tid;
+        if (o >= DA_ROWS * 12) continue;
+        const int j = o / 12, k = o - j * 12;
+        float s = outv[q];
+        if (j == NJ) {
+            s = 0.f;
+            if ((k & 3) == 3) {
+                s = sG[0][k >> 2];
+                for (int w = 1; w < DS_THREADS / 64; ++w) s += sG[w][k >> 2];
+            }
+        }
+        out[o] = s;
+    }
+}
+
 int saga_launch_skin_fwd(const saga_model* m, const float* A, const float* v_posed, const float* transl, float* verts, int B,
                          hipStream_t st) {
     const int per_block = SKIN_THREADS * SKIN_VPT;
@@ -487,6 +684,30 @@ __global__ void da_sum_kernel(const float* __restrict__ part, float* __restrict_
 // scratch: >= 3 * B * dA_stride floats, free for the duration of the call (the split-K slabs, written later), or NULL
 int saga_launch_skin_bwd(const saga_model* m, const float* A, const float* g_verts, const float* v_posed, float* g_vposed,
                          float* dA, int dA_stride, float* scratch, int B, hipStream_t st) {
+    static const int force_mfma = getenv("SAGA_DA_MFMA") != nullptr;      // cross-check switch: the dense MFMA reduction
+    if (m->ds_parts > 0 && scratch && !force_mfma) {
+        // two blocks per candidate (a fixed split, whatever the batch: a candidate's sums must not depend on the batch around it)
+        const int halves = m->ds_parts >= 4 ? 2 : 1;
+        const int rpb = (m->ds_parts + halves - 1) / halves;
+        const size_t part_stride = (size_t)B * dA_stride;
+        float* out = halves > 1 ? scratch : dA;
+        dim3 grid(B, halves);
+        if (m->KW == 4)
+            skin_bwd_sparse_kernel<true><<<grid, DS_THREADS, 0, st>>>(g_verts, v_posed, A, m->w_idx, m->w_val, m->ds_ent, m->ds_meta,
+                                                                      m->ds_item_ptr, g_vposed, out, m->V, m->Npad, m->KW, m->ds_vr,
+                                                                      m->ds_parts, rpb, dA_stride, part_stride);
+        else
+            skin_bwd_sparse_kernel<false><<<grid, DS_THREADS, 0, st>>>(g_verts, v_posed, A, m->w_idx, m->w_val, m->ds_ent, m->ds_meta,
+                                                                       m->ds_item_ptr, g_vposed, out, m->V, m->Npad, m->KW, m->ds_vr,
+                                                                       m->ds_parts, rpb, dA_stride, part_stride);
+        SAGA_LAUNCH_CHECK();
+        if (halves > 1) {
+            const int n = B * (DA_ROWS * 12);
+            da_sum_kernel<<<(n + 255) / 256, 256, 0, st>>>(scratch, dA, B, dA_stride, halves, part_stride);
+            SAGA_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     const int per_block = SKIN_THREADS * SKIN_VPT;
     dim3 grid1((m->Npad / 3 + 1 + per_block - 1) / per_block, B);     // covers every column of [0, Npad)
     const int blocks = (B + DA_CANDS - 1) / DA_CANDS;

@@ -66,7 +66,7 @@ def _random_faces(rng, n_verts, n_faces):
 
 
 def make_body_model(seed=7, n_verts=NUM_VERTS_SMPLX, n_faces=NUM_FACES_SMPLX,
-                    weights_nnz=4, dense_weights=False, n_shape=20, dtype=np.float32):
+                    weights_nnz=4, dense_weights=False, local_weights=False, n_shape=20, dtype=np.float32):
     """Random arrays with the layout of a SMPL-X ``.npz`` (10 shape + 10 expression dirs)."""
     rng = np.random.default_rng(seed)
     V, J = int(n_verts), NUM_JOINTS
@@ -84,6 +84,14 @@ def make_body_model(seed=7, n_verts=NUM_VERTS_SMPLX, n_faces=NUM_FACES_SMPLX,
 
     if dense_weights:
         weights = rng.uniform(0.0, 1.0, size=(V, J)) ** 4
+    elif local_weights:
+        # mesh-like structure: runs of consecutive vertices share their joints (as the vertices of a body part do), instead
+        # of every vertex drawing its own random joints (the default: the worst case for anything that caches transforms)
+        weights = np.zeros((V, J))
+        k = min(weights_nnz, J)
+        first = (np.arange(V) * J) // V
+        for d in range(k):
+            weights[np.arange(V), (first + d) % J] = rng.uniform(0.05, 1.0, V)
     else:
         weights = np.zeros((V, J))
         k = min(weights_nnz, J)
