@@ -60,7 +60,8 @@ __global__ __launch_bounds__(NTH) void nn_scan_kernel(const float* __restrict__ 
 // minimum and its index are carried across tiles with a strict '<', tiles in index order).  Same outputs as
 // nn_scan_kernel, bit for bit.  One tile for every call SAGA makes (2,048 object points / 778 hand vertices); dense
 // clouds (BASELINE config 5: 100,000 points) stream through LDS 2,048 points at a time.
-template <int NQ, int NTH>
+// MF: approximate pass on the matrix cores (nnf_scan_mfma) instead of the vector units (nnf_scan); same results.
+template <int NQ, int NTH, bool MF>
 __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 1) void nn_fast_kernel(const float* __restrict__ q, const float* __restrict__ db,
                                                       float* __restrict__ dist, int32_t* __restrict__ idx, int Pq, int Pd) {
     __shared__ __attribute__((aligned(16))) float sdb[NNF_TILE_FLOATS(NN_TILE)];
@@ -87,8 +88,9 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 1) void nn_fast_kernel(const 
 #pragma unroll
         for (int i = 0; i < NQ; ++i) { qx[i] = ox[i] - f.cx; qy[i] = oy[i] - f.cy; qz[i] = oz[i] - f.cz; }
         __syncthreads();
-        nnf_scan<NQ>(sdb, cnt_pad / NNF_CH, qx, qy, qz, m1, m2, m3, c1, c2);
-        nnf_resolve<NQ>(sdb, cnt_pad / NNF_CH, f, t0, qx, qy, qz, ox, oy, oz, m1, m2, m3, c1, c2, best, bi);
+        if (MF) nnf_scan_mfma<NQ>(sdb, cnt_pad / NNF_CH, f, qx, qy, qz, m1, m2, m3, c1, c2);
+        else nnf_scan<NQ>(sdb, cnt_pad / NNF_CH, qx, qy, qz, m1, m2, m3, c1, c2);
+        nnf_resolve<NQ, MF>(sdb, cnt_pad / NNF_CH, f, t0, qx, qy, qz, ox, oy, oz, m1, m2, m3, c1, c2, best, bi);
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -104,19 +106,19 @@ static int launch_scan(const float* q, const float* db, float* dist, int32_t* id
     if (!dist && !idx) return 0;
     // SAGA_NN_EXACT_SCAN=1 forces the plain 6-op exact scan (cross-checks of the two code paths)
     const char* force = getenv("SAGA_NN_EXACT_SCAN");
+    // SAGA_NN_VALU_PASS=1 keeps the two-level scan but runs its approximate pass on the vector units (cross-check of the two passes)
+    static const bool valu_pass = getenv("SAGA_NN_VALU_PASS") != nullptr;
     if (!(force && force[0] == '1')) {
-        if (Pq <= 128) {
-            nn_fast_kernel<2, 64><<<dim3(1, N), 64, 0, st>>>(q, db, dist, idx, Pq, Pd);
-        } else if (Pq <= 256) {
-            nn_fast_kernel<2, 128><<<dim3(1, N), 128, 0, st>>>(q, db, dist, idx, Pq, Pd);
-        } else if (Pq <= 512) {
-            nn_fast_kernel<2, 256><<<dim3(1, N), 256, 0, st>>>(q, db, dist, idx, Pq, Pd);
-        } else {
-            // 4 queries per lane (8 would need > 128 VGPRs: the scan wants 3-4 waves per SIMD more than it wants
-            // fewer broadcast LDS reads); clouds of more than 1,024 queries take several blocks per batch element
-            dim3 grid((Pq + 256 * 4 - 1) / (256 * 4), N);
-            nn_fast_kernel<4, 256><<<grid, 256, 0, st>>>(q, db, dist, idx, Pq, Pd);
-        }
+        // 4 queries per lane for large query clouds (8 would need > 128 VGPRs: the scan wants 3-4 waves per SIMD more than it
+        // wants fewer broadcast LDS reads); clouds of more than 1,024 queries take several blocks per batch element
+        const dim3 grid4((Pq + 256 * 4 - 1) / (256 * 4), N);
+#define NNF_LAUNCH(MF)                                                                                        \
+        if (Pq <= 128) nn_fast_kernel<2, 64, MF><<<dim3(1, N), 64, 0, st>>>(q, db, dist, idx, Pq, Pd);           \
+        else if (Pq <= 256) nn_fast_kernel<2, 128, MF><<<dim3(1, N), 128, 0, st>>>(q, db, dist, idx, Pq, Pd);    \
+        else if (Pq <= 512) nn_fast_kernel<2, 256, MF><<<dim3(1, N), 256, 0, st>>>(q, db, dist, idx, Pq, Pd);    \
+        else nn_fast_kernel<4, 256, MF><<<grid4, 256, 0, st>>>(q, db, dist, idx, Pq, Pd);
+        if (valu_pass) { NNF_LAUNCH(false) } else { NNF_LAUNCH(true) }
+#undef NNF_LAUNCH
         SAGA_LAUNCH_CHECK();
         return 0;
     }

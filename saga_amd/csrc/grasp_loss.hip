@@ -289,27 +289,10 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
         for (int i = 0; i < GL_NQ; ++i) { cx[i] = qx[i] - fo.cx; cy[i] = qy[i] - fo.cy; cz[i] = qz[i] - fo.cz; }
 #pragma unroll
         for (int i = 0; i < GL_NQ; ++i) { best[i] = INFINITY; bi[i] = 0; }
-        // 778 + 143 = 921 queries fill 15 of the block's 16 wave-slots: the wave whose last slot holds no query at all
-        // (wave-uniform) scans three queries per lane instead of four
-        if ((GL_NQ - 1) * GL_THREADS + (tid & ~63) < NQ) {
-            nnf_scan<GL_NQ>(sObj, Opad / NNF_CH, cx, cy, cz, m1, m2, m3, c1, c2);
-            GL_T(2);
-            nnf_resolve<GL_NQ>(sObj, Opad / NNF_CH, fo, 0, cx, cy, cz, qx, qy, qz, m1, m2, m3, c1, c2, best, bi);
-        } else {
-            constexpr int N3 = GL_NQ - 1;
-            float ax[N3], ay[N3], az[N3], ox3[N3], oy3[N3], oz3[N3], n1[N3], n2[N3], n3[N3], b3[N3];
-            int d1[N3], d2[N3], i3[N3];
-#pragma unroll
-            for (int i = 0; i < N3; ++i) {
-                ax[i] = cx[i]; ay[i] = cy[i]; az[i] = cz[i]; ox3[i] = qx[i]; oy3[i] = qy[i]; oz3[i] = qz[i];
-                b3[i] = INFINITY; i3[i] = 0;
-            }
-            nnf_scan<N3>(sObj, Opad / NNF_CH, ax, ay, az, n1, n2, n3, d1, d2);
-            GL_T(2);
-            nnf_resolve<N3>(sObj, Opad / NNF_CH, fo, 0, ax, ay, az, ox3, oy3, oz3, n1, n2, n3, d1, d2, b3, i3);
-#pragma unroll
-            for (int i = 0; i < N3; ++i) { best[i] = b3[i]; bi[i] = i3[i]; }
-        }
+        // approximate pass on the matrix cores (f16-split operands, nn_fast.h), exact pass on the two candidate chunks
+        nnf_scan_mfma<GL_NQ>(sObj, Opad / NNF_CH, fo, cx, cy, cz, m1, m2, m3, c1, c2);
+        GL_T(2);
+        nnf_resolve<GL_NQ, true>(sObj, Opad / NNF_CH, fo, 0, cx, cy, cz, qx, qy, qz, m1, m2, m3, c1, c2, best, bi);
         GL_T(3);
 #pragma unroll
         for (int i = 0; i < GL_NQ; ++i) {
@@ -371,10 +354,10 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
             ox[i] = ob[k * 3]; oy[i] = ob[k * 3 + 1]; oz[i] = ob[k * 3 + 2];
             cx[i] = ox[i] - fh.cx; cy[i] = oy[i] - fh.cy; cz[i] = oz[i] - fh.cz;
         }
-        nnf_scan<GLF_NO>(sHand, Hpad / NNF_CH, cx, cy, cz, m1, m2, m3, c1, c2);
+        nnf_scan_mfma<GLF_NO>(sHand, Hpad / NNF_CH, fh, cx, cy, cz, m1, m2, m3, c1, c2);
 #pragma unroll
         for (int i = 0; i < GLF_NO; ++i) { best[i] = INFINITY; bj[i] = 0; }
-        nnf_resolve<GLF_NO>(sHand, Hpad / NNF_CH, fh, 0, cx, cy, cz, ox, oy, oz, m1, m2, m3, c1, c2, best, bj);
+        nnf_resolve<GLF_NO, true>(sHand, Hpad / NNF_CH, fh, 0, cx, cy, cz, ox, oy, oz, m1, m2, m3, c1, c2, best, bj);
 #pragma unroll
         for (int i = 0; i < GLF_NO; ++i) {
             const int k = k0 + tid + i * GL_THREADS;

@@ -188,6 +188,142 @@ __device__ __forceinline__ void nnf_scan(const float* __restrict__ s, int n_chun
     }
 }
 
+// ---- approximate pass on the matrix cores ---------------------------------------------------------------------------------
+// Same contract as nnf_scan (per lane: NQ framed queries in, the three smallest chunk minima and the chunks of the first two
+// out, chunks = NNF_CH consecutive points), but t(p) for 32 points x 32 queries comes from ONE v_mfma_f32_32x32x16_f16:
+// every f32 operand is split into two f16 parts (x = xh + xl, |x - xh - xl| <= 2^-22 |x|) after scaling by a power of two,
+// and the 16 k-slots carry every partial product plus |p|^2 in three parts:
+//     A (point)  [ahx ahy ahz ahx ahy ahz alx aly | alz wh wm wl alx aly alz P]        a = -2 (p - c) sa,  w = |p - c|^2 sa sq
+//     B (query)  [qhx qhy qhz qlx qly qlz qhx qhy | qhz 1  1  1  qlx qly qlz 1]        q = (q - c) sq
+// (P = 0; pad points: a = 0, wh = wm = wl = P = 65504 -> larger than any real t).  f16 x f16 products are exact in f32; the
+// matrix core accumulates in f32.  A wave64 holds output column (lane & 31) = query and rows {(r&3) + 8(r>>2) + 4(lane>>5)};
+// tile row rho carries point 16((rho>>2)&1) + 4(rho>>3) + (rho&3) of the 32, so the 16 values a lane sees are exactly chunk
+// 2*tile + (lane>>5): the lane-local minimum of the 16 accumulator registers IS the chunk minimum, and the exact pass
+// (nnf_resolve) is unchanged.  The two lanes that share a query (l, l^32) merge their sorted triples at the end.
+// Error: |t_mfma / S - t| <= 2^-21 |a||q| (splits) + 2^-19 (|a||q| + w) (16 accumulation roundings, truncation allowed)
+//        <= NNF_MFMA_KAPPA Rp (Rp + 2 |q - c|) with 2.6x slack; scripts/ab/nn_mfma16_ab.hip measures it against float64.
+// The A operand is rebuilt per wave from the f32 tile (no second LDS image: the block keeps its occupancy).
+typedef _Float16 nn_h8 __attribute__((ext_vector_type(8)));
+typedef float nn_f16v __attribute__((ext_vector_type(16)));
+#define NNF_MFMA_KAPPA 7.62939453125e-6f      // 2^-17
+
+__device__ __forceinline__ float nnf_pow2_scale(float r) {      // 2^(7-e) for r = m 2^e, m in [1,2): r * scale in [128, 256)
+    int e = (__float_as_int(r) >> 23) & 0xff;
+    e = min(max(e, 127 - 40), 127 + 40);
+    return __int_as_float((261 - e) << 23);
+}
+
+__device__ __forceinline__ void nnf_insert3(float m, int c, float& m1, float& m2, float& m3, int& c1, int& c2) {
+    const bool lt1 = m < m1, lt2 = m < m2;
+    m3 = __builtin_amdgcn_fmed3f(m, m2, m3);
+    m2 = __builtin_amdgcn_fmed3f(m, m1, m2);
+    m1 = __builtin_elementwise_minimum(m, m1);
+    int n2 = lt2 ? c : c2;
+    n2 = lt1 ? c1 : n2;
+    c2 = n2;
+    c1 = lt1 ? c : c1;
+}
+
+__device__ __forceinline__ void nnf_split16(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+template <int NQ>
+__device__ __forceinline__ void nnf_scan_mfma(const float* __restrict__ s, int n_chunks, const NnfFrame& f, const float (&qx)[NQ],
+                                              const float (&qy)[NQ], const float (&qz)[NQ], float (&m1)[NQ], float (&m2)[NQ],
+                                              float (&m3)[NQ], int (&c1)[NQ], int (&c2)[NQ]) {
+    const int lane = __lane_id(), col = lane & 31, h = lane >> 5;
+    // scales (powers of two): 2 Rp sa in [128, 256); max|q| sq < 256 and Rp sq < 256, so that w = |p|^2 sa sq < 32768
+    float rq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) rq = fmaxf(rq, fmaxf(fabsf(qx[i]), fmaxf(fabsf(qy[i]), fabsf(qz[i]))));
+    for (int o = 32; o > 0; o >>= 1) rq = fmaxf(rq, __shfl_xor(rq, o, 64));
+    const float sa = nnf_pow2_scale(2.f * f.rp);
+    const float sq = fminf(nnf_pow2_scale(rq), nnf_pow2_scale(f.rp));
+    const float S = sa * sq, inv_S = 1.f / S;
+    // B operands: tile (i, hh) = query i of lanes hh*32 .. hh*32+31
+    nn_h8 Bq[NQ][2];
+    const _Float16 one = (_Float16)1.f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int src = hh * 32 + col;
+            _Float16 xh, xl, yh, yl, zh, zl;
+            nnf_split16(__shfl(qx[i], src, 64) * sq, xh, xl);
+            nnf_split16(__shfl(qy[i], src, 64) * sq, yh, yl);
+            nnf_split16(__shfl(qz[i], src, 64) * sq, zh, zl);
+            const nn_h8 lo = {xh, yh, zh, xl, yl, zl, xh, yh}, hi = {zh, one, one, one, xl, yl, zl, one};
+            Bq[i][hh] = h ? hi : lo;
+        }
+    float M1[NQ][2], M2[NQ][2], M3[NQ][2];
+    int C1[NQ][2], C2[NQ][2];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) { M1[i][hh] = INFINITY; M2[i][hh] = INFINITY; M3[i][hh] = INFINITY; C1[i][hh] = -1; C2[i][hh] = -1; }
+
+    const int n_pts = n_chunks * NNF_CH, n_tiles = (n_chunks + 1) >> 1;
+    const int prow = 16 * ((col >> 2) & 1) + 4 * (col >> 3) + (col & 3);      // point of the tile this lane's A row carries
+    const nn_f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const _Float16 big = (_Float16)65504.f, hz = (_Float16)0.f;
+    auto build_A = [&](int tile) -> nn_h8 {
+        const int p = min(tile * 32 + prow, n_pts - 1);
+        const float* d = s + (p >> 4) * NNF_CSTRIDE + ((p & 15) >> 1) * 8 + (p & 1);
+        const float X = d[0], Y = d[2], Z = d[4], W = d[6];
+        const bool pad = !(fabsf(X) < 1.0e17f);
+        _Float16 axh, axl, ayh, ayl, azh, azl, wh, wm, wl;
+        nnf_split16(pad ? 0.f : X * sa, axh, axl);
+        nnf_split16(pad ? 0.f : Y * sa, ayh, ayl);
+        nnf_split16(pad ? 0.f : Z * sa, azh, azl);
+        const float w = pad ? 0.f : W * S;
+        wh = (_Float16)w;
+        const float r1 = w - (float)wh;
+        wm = (_Float16)r1;
+        wl = (_Float16)(r1 - (float)wm);
+        if (pad) { wh = big; wm = big; wl = big; }
+        const nn_h8 alo = {axh, ayh, azh, axh, ayh, azh, axl, ayl}, ahi = {azl, wh, wm, wl, axl, ayl, azl, pad ? big : hz};
+        return h ? ahi : alo;
+    };
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const nn_h8 A = build_A(tile);
+        const int c = 2 * tile + h;
+        const bool valid = c < n_chunks;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            // two MFMAs in flight, then their two reductions; the scheduling fence keeps the compiler from issuing all 2 NQ
+            // MFMAs first (16 accumulator registers each)
+            const nn_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, Bq[i][0], zero16, 0, 0, 0);
+            const nn_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, Bq[i][1], zero16, 0, 0, 0);
+            // v_minimum3_f32 (IEEE-754-2019 minimum: no canonicalisation of the accumulator registers needed)
+            float ma = __builtin_elementwise_minimum(D0[0], D0[1]), mb = __builtin_elementwise_minimum(D1[0], D1[1]);
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) ma = __builtin_elementwise_minimum(__builtin_elementwise_minimum(ma, D0[r]), D0[r + 1]);
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) mb = __builtin_elementwise_minimum(__builtin_elementwise_minimum(mb, D1[r]), D1[r + 1]);
+            ma = valid ? ma : INFINITY;
+            mb = valid ? mb : INFINITY;
+            nnf_insert3(ma, c, M1[i][0], M2[i][0], M3[i][0], C1[i][0], C2[i][0]);
+            nnf_insert3(mb, c, M1[i][1], M2[i][1], M3[i][1], C1[i][1], C2[i][1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // the lane's own query i was scanned in tile (i, h): its rows by this lane, the other 16 of every 32 by lane ^ 32
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        float a1 = h ? M1[i][1] : M1[i][0], a2 = h ? M2[i][1] : M2[i][0], a3 = h ? M3[i][1] : M3[i][0];
+        int k1 = h ? C1[i][1] : C1[i][0], k2 = h ? C2[i][1] : C2[i][0];
+        const float b1 = __shfl_xor(h ? M1[i][0] : M1[i][1], 32, 64), b2 = __shfl_xor(h ? M2[i][0] : M2[i][1], 32, 64),
+                    b3 = __shfl_xor(h ? M3[i][0] : M3[i][1], 32, 64);
+        const int j1 = __shfl_xor(h ? C1[i][0] : C1[i][1], 32, 64), j2 = __shfl_xor(h ? C2[i][0] : C2[i][1], 32, 64);
+        nnf_insert3(b1, j1, a1, a2, a3, k1, k2);
+        nnf_insert3(b2, j2, a1, a2, a3, k1, k2);
+        nnf_insert3(b3, -1, a1, a2, a3, k1, k2);       // only its value can matter (as m3)
+        m1[i] = a1 * inv_S; m2[i] = a2 * inv_S; m3[i] = a3 * inv_S; c1[i] = k1; c2[i] = k2;
+    }
+}
+
 // exact evaluation of one chunk for one query (original coordinates o*), index order, strict '<'.  Two points per packed
 // instruction; every packed lane performs the IEEE operation of nn_dist2, so the values are those of the scalar chain.
 __device__ __forceinline__ void nnf_exact_chunk(const float* __restrict__ s, const NnfFrame& f, int ch, int base, float ox, float oy,
@@ -214,7 +350,8 @@ __device__ __forceinline__ void nnf_exact_chunk(const float* __restrict__ s, con
 // starts them at +INF / 0): exact squared distance and index of the sequential exact scan over every tile so far
 // (global index of point 0 of this tile = base; tiles must come in index order).  Every lane of the wave must call it
 // together (the slow path is a wave-wide loop).
-template <int NQ>
+// MFMA_PASS: the chunk minima come from nnf_scan_mfma (its error bound replaces the vector pass's).
+template <int NQ, bool MFMA_PASS = false>
 __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_chunks, const NnfFrame& f, int base,
                                             const float (&qx)[NQ], const float (&qy)[NQ], const float (&qz)[NQ],
                                             const float (&ox)[NQ], const float (&oy)[NQ], const float (&oz)[NQ],
@@ -225,7 +362,8 @@ __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_c
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const float qq = __builtin_fmaf(qz[i], qz[i], __builtin_fmaf(qy[i], qy[i], qx[i] * qx[i])) * 1.001f;
-        const float E = 5.9604645e-7f * f.rp * (f.rp + sqrtf(qq));                       // 10 u Rp (Rp + Rq)
+        const float E = MFMA_PASS ? NNF_MFMA_KAPPA * f.rp * (f.rp + 2.f * sqrtf(qq))
+                                  : 5.9604645e-7f * f.rp * (f.rp + sqrtf(qq));           // 10 u Rp (Rp + Rq)
         const float thr = m1[i] + (2.f * E + 1.0e-6f * (fmaxf(m1[i] + qq, 0.f) + E));
         // a tile whose best possible distance cannot beat the exact minimum carried in from earlier tiles is skipped:
         // D(p) >= t(p) - E + |q - c|^2 (1 - 3u) for every point of this tile, and its fp32 distance is >= D (1 - 6u)
