@@ -227,7 +227,7 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     const float* __restrict__ c_obj, float* __restrict__ terms, float* __restrict__ markers_rec,
     float* __restrict__ hand_rec, float* __restrict__ hand_normals, float* __restrict__ h2o_marker,
     float* __restrict__ h2o_signed, float* __restrict__ o2h_signed, int32_t* __restrict__ idx_m2o,
-    int32_t* __restrict__ idx_h2o, int32_t* __restrict__ idx_o2h, int V, int O) {
+    int32_t* __restrict__ idx_h2o, int32_t* __restrict__ idx_o2h, int V, int O, int touch_verts) {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) float sObj[NNF_TILE_FLOATS(GL_TILE)];        // framed object tile; later the hand normals
     __shared__ __attribute__((aligned(16))) float sHand[NNF_TILE_FLOATS(GL_MAX_HAND)];   // framed hand tile
@@ -333,13 +333,34 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
 
     GL_T(4);
     // ---- hand normals (area-weighted, ascending face order) into the LDS space the object tile no longer needs ----
+    // The normals gather three corners per incident face.  When the mesh's faces join vertices that are far apart in memory
+    // (touch_verts: set by the host from the model's faces), those are ~14k scattered 12-B reads per candidate that miss L2
+    // (4x the bytes the candidate has).  Touching every 128-B line of the candidate's vertex block once, coalesced, brings
+    // the block (126 KB) into L2 first.
+    if (touch_verts) {
+        const int n_lines = (V * 3 + 31) / 32;
+        for (int l = tid; l < n_lines; l += GL_THREADS) {
+            const float x = vb[min(l * 32, V * 3 - 1)];
+            asm volatile("" ::"v"(x));
+        }
+    }
     __syncthreads();
-    for (int i = tid; i < H; i += GL_THREADS) {
-        float nx, ny, nz;
-        saga_vertex_normal(vb, vf_ptr, vf_tri, tb.hand_ids[i], nx, ny, nz);
-        sNrm[i * 3] = nx; sNrm[i * 3 + 1] = ny; sNrm[i * 3 + 2] = nz;
-        float* dst = hand_normals + ((size_t)b * H + i) * 3;
-        dst[0] = nx; dst[1] = ny; dst[2] = nz;
+    {
+        // all of a lane's hand vertices (GL_MAX_HAND / GL_THREADS = 4) at once: their read chains advance together
+        constexpr int NVL = GL_MAX_HAND / GL_THREADS;
+        int hv[NVL];
+        float nr[NVL][3];
+#pragma unroll
+        for (int r = 0; r < NVL; ++r) hv[r] = (tid + r * GL_THREADS < H) ? tb.hand_ids[tid + r * GL_THREADS] : -1;
+        saga_vertex_normals_multi<NVL>(vb, vf_ptr, vf_tri, hv, nr);
+#pragma unroll
+        for (int r = 0; r < NVL; ++r) {
+            const int i = tid + r * GL_THREADS;
+            if (i >= H) continue;
+            sNrm[i * 3] = nr[r][0]; sNrm[i * 3 + 1] = nr[r][1]; sNrm[i * 3 + 2] = nr[r][2];
+            float* dst = hand_normals + ((size_t)b * H + i) * 3;
+            dst[0] = nr[r][0]; dst[1] = nr[r][1]; dst[2] = nr[r][2];
+        }
     }
     __syncthreads();
 
@@ -529,7 +550,7 @@ extern "C" int saga_grasp_loss_fwd(const saga_model_t* m, const saga_grasp_table
         grasp_loss_fwd_fast_kernel<<<B, GL_THREADS, 0, (hipStream_t)stream>>>(*tb, verts, m->vf_ptr, m->vf_tri, obj,
                                                                               obj_normals, markers_target, c_markers, c_object, terms,
                                                                               markers_rec, hand_rec, hand_normals, h2o_marker,
-                                                                              h2o_signed, o2h_signed, idx_m2o, idx_h2o, idx_o2h, m->V, O);
+                                                                              h2o_signed, o2h_signed, idx_m2o, idx_h2o, idx_o2h, m->V, O, m->scattered_faces);
     else
         grasp_loss_fwd_kernel<<<B, GL_THREADS, 0, (hipStream_t)stream>>>(*tb, verts, m->vf_ptr, m->vf_tri, obj, obj_normals,
                                                                          markers_target, c_markers, c_object, terms, markers_rec,

@@ -216,6 +216,15 @@ static int model_create_impl(saga_model_t** out, const saga_model_desc_t* d, con
             F = (int)(faces.size() / 3);
         }
         m->F = F;
+        {
+            size_t far = 0;
+            for (int f = 0; f < F; ++f) {
+                const int a = faces[f * 3], b = faces[f * 3 + 1], c = faces[f * 3 + 2];
+                const int lo = std::min(a, std::min(b, c)), hi = std::max(a, std::max(b, c));
+                far += (hi - lo) > 1024;
+            }
+            m->scattered_faces = F > 0 && far * 2 > (size_t)F;
+        }
         std::vector<int32_t> vptr(V + 1, 0), vidx((size_t)3 * F);
         for (int f = 0; f < 3 * F; ++f) vptr[faces[f] + 1]++;
         for (int v = 0; v < V; ++v) vptr[v + 1] += vptr[v];

@@ -80,6 +80,7 @@ struct saga_model {
     int32_t* ds_meta;     // [ds_parts][2]: offset of the range's entries in ds_ent, C
     int32_t* ds_item_ptr; // [ds_parts][NJ+1]: first item of each joint
     // faces / landmarks / extra joints
+    int scattered_faces; // 1 when most faces join vertices more than 1,024 ids apart (kernels that gather face corners then warm L2 first)
     int32_t* faces;     // [F,3]
     int32_t* vf_ptr;    // [V+1] CSR vertex -> incident (face, corner) in ascending face order
     int32_t* vf_idx;    // [3F]  face id

@@ -40,3 +40,58 @@ __device__ __forceinline__ void saga_vertex_normal(const float* __restrict__ vb,
     if (isnan(nx)) { nx = 0.f; ny = 0.f; nz = 1.f; }
     ox = nx; oy = ny; oz = nz;
 }
+
+// NV vertices per lane at once (ids v[k], k < NV; v[k] < 0 = none): the same sums in the same order as saga_vertex_normal, but the
+// NV chains of dependent reads (incidence range -> face ids -> corner coordinates) advance together, two faces per vertex and
+// step, so a lane waits for 1/NV as many memory round trips.
+template <int NV>
+__device__ __forceinline__ void saga_vertex_normals_multi(const float* __restrict__ vb, const int32_t* __restrict__ vf_ptr,
+                                                          const int32_t* __restrict__ vf_tri, const int (&v)[NV], float (&out)[NV][3]) {
+#pragma clang fp contract(off)
+    int e0[NV], e1[NV];
+    float n[NV][3];
+    int steps = 0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int vk = max(v[k], 0);
+        e0[k] = vf_ptr[vk]; e1[k] = v[k] >= 0 ? vf_ptr[vk + 1] : e0[k];
+        n[k][0] = 0.f; n[k][1] = 0.f; n[k][2] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) steps = max(steps, (e1[k] - e0[k] + 1) >> 1);
+    for (int g = 0; g < steps; ++g) {
+        int4 t[NV][2];
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) t[k][u] = reinterpret_cast<const int4*>(vf_tri)[max(min(e0[k] + 2 * g + u, e1[k] - 1), 0)];
+        float3 p[NV][2][3];
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                p[k][u][0] = *reinterpret_cast<const float3*>(vb + (size_t)t[k][u].x * 3);
+                p[k][u][1] = *reinterpret_cast<const float3*>(vb + (size_t)t[k][u].y * 3);
+                p[k][u][2] = *reinterpret_cast<const float3*>(vb + (size_t)t[k][u].z * 3);
+            }
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (e0[k] + 2 * g + u >= e1[k]) continue;
+                const float ax = p[k][u][1].x - p[k][u][0].x, ay = p[k][u][1].y - p[k][u][0].y, az = p[k][u][1].z - p[k][u][0].z;
+                const float bx = p[k][u][2].x - p[k][u][0].x, by = p[k][u][2].y - p[k][u][0].y, bz = p[k][u][2].z - p[k][u][0].z;
+                n[k][0] += ay * bz - az * by;
+                n[k][1] += az * bx - ax * bz;
+                n[k][2] += ax * by - ay * bx;
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        float nx = n[k][0], ny = n[k][1], nz = n[k][2];
+        const float sq = nx * nx + ny * ny + nz * nz;
+        if (sq > 0.f) { const float inv = 1.0f / sqrtf(sq); nx *= inv; ny *= inv; nz *= inv; }
+        if (isnan(nx)) { nx = 0.f; ny = 0.f; nz = 1.f; }
+        out[k][0] = nx; out[k][1] = ny; out[k][2] = nz;
+    }
+}
