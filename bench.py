@@ -52,10 +52,11 @@ def stage_rooflines(prof, steps, B, n_obj, V=10475):
     vb = 3 * V * 4.0                                           # bytes of one [V,3] row
     add('skin_fwd', 'skin_fwd', 'hbm', B * 2 * vb, 'GB/s', PEAK_HBM_GBS)                 # read v_posed, write vertices
     add('skin_bwd', 'skin_bwd', 'hbm', B * 3 * vb, 'GB/s', PEAK_HBM_GBS)                 # read g_vertices + v_posed, write g_v_posed
-    add('skin_bwd_dA_mfma', 'skin_bwd', 'mfma', B * 2.0 * V * 12 * 55, 'TFLOP/s', PEAK_F32_TFLOPS)
     add('grasp_loss_bwd', 'grasp_loss_bwd', 'hbm', B * vb, 'GB/s', PEAK_HBM_GBS)         # dense g_vertices written once
     add('pose_chain_fwd', 'pose_fwd', 'hbm', B * (512 + 55 * 36 + 165) * 4.0, 'GB/s', PEAK_HBM_GBS)
-    # NN: (143 + 778) x O point pairs per candidate, 8 FLOP each (3 sub, 1 mul, 2 fma), one pass serving both directions
+    # NN: (143 + 778) x O point pairs per candidate, 8 FLOP each (3 sub, 1 mul, 2 fma), one pass serving both directions -- the
+    # SURVEY 8d figure, priced against the FP32 vector peak.  (The kernel evaluates both directions, 3.48 M pairs per candidate;
+    # its approximate pass runs on the matrix cores, the exact pass and the bookkeeping on the vector units.)
     add('grasp_loss_fwd_nn', 'grasp_loss_fwd', 'valu', B * (143 + 778) * n_obj * 8.0, 'TFLOP/s', PEAK_F32_TFLOPS)
     return out
 
