@@ -200,12 +200,15 @@ __device__ __forceinline__ void nnf_scan(const float* __restrict__ s, int n_chun
 // tile row rho carries point 16((rho>>2)&1) + 4(rho>>3) + (rho&3) of the 32, so the 16 values a lane sees are exactly chunk
 // 2*tile + (lane>>5): the lane-local minimum of the 16 accumulator registers IS the chunk minimum, and the exact pass
 // (nnf_resolve) is unchanged.  The two lanes that share a query (l, l^32) merge their sorted triples at the end.
-// Error: |t_mfma / S - t| <= 2^-21 |a||q| (splits) + 2^-19 (|a||q| + w) (16 accumulation roundings, truncation allowed)
-//        <= NNF_MFMA_KAPPA Rp (Rp + 2 |q - c|) with 2.6x slack; scripts/ab/nn_mfma16_ab.hip measures it against float64.
+// Error: the matrix core keeps f16 subnormals and adds the 16 exact products in a wide accumulator with one final rounding
+// (scripts/ab/mfma_f16_denorm.hip), so |t_mfma / S - t| <= 2^-21 |a||q| (the residuals of the two-part splits) + 2^-24 |t|
+// (the rounding) + O(2^-25) absolute per subnormal low part <= 2^-20.8 Rp (Rp + 2 |q - c|).  NNF_MFMA_KAPPA = 2^-19 leaves 3.5x
+// on that and 13x on the largest error scripts/ab/nn_mfma16_ab.hip measures against float64 (2^-22.7); a sequential fp32
+// accumulation with truncation at every step would give 2^-18.8.
 // The A operand is rebuilt per wave from the f32 tile (no second LDS image: the block keeps its occupancy).
 typedef _Float16 nn_h8 __attribute__((ext_vector_type(8)));
 typedef float nn_f16v __attribute__((ext_vector_type(16)));
-#define NNF_MFMA_KAPPA 7.62939453125e-6f      // 2^-17
+#define NNF_MFMA_KAPPA 1.9073486328125e-6f    // 2^-19
 
 __device__ __forceinline__ float nnf_pow2_scale(float r) {      // 2^(7-e) for r = m 2^e, m in [1,2): r * scale in [128, 256)
     int e = (__float_as_int(r) >> 23) & 0xff;
