@@ -85,6 +85,45 @@ def test_chamfer_two_level_scan_adversarial(case):
     _check(x.float().contiguous(), y.float().contiguous())
 
 
+@pytest.mark.parametrize('P2', [1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 2047, 2048, 2049, 2064, 2065, 4096])
+def test_chamfer_sizes_around_chunk_and_tile_edges(P2):
+    """The matrix-core pass walks the database 32 points (two 16-point chunks) at a time, LDS tiles hold 2,048: sizes on
+    both sides of every edge, in both roles (the reverse direction scans the 70-point cloud)."""
+    g = torch.Generator().manual_seed(P2)
+    _check(torch.randn(2, 70, 3, generator=g) * 0.1, torch.randn(2, P2, 3, generator=g) * 0.1 + 0.02)
+
+
+@pytest.mark.parametrize('case', ['tiny_cloud', 'far_queries', 'flat_cloud', 'line_cloud', 'mixed_scales', 'one_point_many_times'])
+def test_chamfer_matrix_pass_scaling(case):
+    """Operand scaling / f16 splitting of the approximate pass (nn_fast.h) at the ends of its range: clouds of radius 1e-6,
+    queries 1e4 radii away, clouds with no extent along one or two axes, near-coincident queries inside a large cloud,
+    a cloud that is one point repeated (radius 0)."""
+    g = torch.Generator().manual_seed(sum(map(ord, case)))
+    N = 2
+    c = torch.tensor([0.3, 0.2, 0.1])
+    if case == 'tiny_cloud':
+        y = torch.randn(N, 1000, 3, generator=g) * 1e-6 + c
+        x = torch.cat([torch.randn(N, 200, 3, generator=g) * 1e-6 + c, torch.randn(N, 100, 3, generator=g) * 0.5 + c], 1)
+    elif case == 'far_queries':
+        y = torch.randn(N, 2048, 3, generator=g) * 0.05 + c
+        x = torch.cat([_sphere(200, g)[None].expand(N, -1, -1) * 500.0 + c, torch.randn(N, 100, 3, generator=g) * 0.05 + c], 1)
+    elif case == 'flat_cloud':
+        y = torch.randn(N, 1500, 3, generator=g) * 0.1 + c
+        y[..., 2] = 0.25
+        x = torch.randn(N, 400, 3, generator=g) * 0.1 + c
+    elif case == 'line_cloud':
+        y = torch.zeros(N, 777, 3) + c
+        y[..., 0] += torch.randn(N, 777, generator=g) * 0.2
+        x = torch.randn(N, 300, 3, generator=g) * 0.2 + c
+    elif case == 'mixed_scales':
+        y = torch.randn(N, 2048, 3, generator=g) * 5.0
+        x = torch.cat([y[:, ::8] + torch.randn(N, 256, 3, generator=g) * 1e-4, torch.randn(N, 100, 3, generator=g) * 5.0], 1)
+    else:
+        y = (torch.zeros(N, 100, 3) + c).contiguous()
+        x = torch.randn(N, 65, 3, generator=g) + c
+    _check(x.float().contiguous(), y.float().contiguous())
+
+
 @pytest.mark.parametrize('N,P1,P2', [(2, 700, 5000), (1, 3000, 20001), (1, 64, 100000)])
 def test_chamfer_dense_clouds_multi_tile(N, P1, P2):
     """Databases larger than one LDS tile (BASELINE config 5 streams 100,000 points): the exact minimum is carried
