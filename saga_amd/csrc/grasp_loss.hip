@@ -220,6 +220,9 @@ extern "C" int saga_debug_read_phases(unsigned long long* out) {
 // tile live in LDS in their own centred frames as (-2x,-2y,-2z,|p|^2); the approximate pass costs 3 fmas per pair, the
 // exact pass re-evaluates the two candidate chunks of every query with the arithmetic of nn_scan.h.
 #define GLF_NO 4                // object points per lane and pass, object -> hand
+#ifndef GL_NRM_FPS
+#define GL_NRM_FPS 2             // faces per vertex and gather step of the hand normals (3: 1.22 ms against 1.10, registers)
+#endif
 __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     saga_grasp_tables_t tb, const float* __restrict__ verts, const int32_t* __restrict__ vf_ptr,
     const int32_t* __restrict__ vf_tri, const float* __restrict__ obj,
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
         float nr[NVL][3];
 #pragma unroll
         for (int r = 0; r < NVL; ++r) hv[r] = (tid + r * GL_THREADS < H) ? tb.hand_ids[tid + r * GL_THREADS] : -1;
-        saga_vertex_normals_multi<NVL>(vb, vf_ptr, vf_tri, hv, nr);
+        saga_vertex_normals_multi<NVL, GL_NRM_FPS>(vb, vf_ptr, vf_tri, hv, nr);
 #pragma unroll
         for (int r = 0; r < NVL; ++r) {
             const int i = tid + r * GL_THREADS;

@@ -44,7 +44,7 @@ __device__ __forceinline__ void saga_vertex_normal(const float* __restrict__ vb,
 // NV vertices per lane at once (ids v[k], k < NV; v[k] < 0 = none): the same sums in the same order as saga_vertex_normal, but the
 // NV chains of dependent reads (incidence range -> face ids -> corner coordinates) advance together, two faces per vertex and
 // step, so a lane waits for 1/NV as many memory round trips.
-template <int NV>
+template <int NV, int FPS = 2>
 __device__ __forceinline__ void saga_vertex_normals_multi(const float* __restrict__ vb, const int32_t* __restrict__ vf_ptr,
                                                           const int32_t* __restrict__ vf_tri, const int (&v)[NV], float (&out)[NV][3]) {
 #pragma clang fp contract(off)
@@ -58,18 +58,18 @@ __device__ __forceinline__ void saga_vertex_normals_multi(const float* __restric
         n[k][0] = 0.f; n[k][1] = 0.f; n[k][2] = 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < NV; ++k) steps = max(steps, (e1[k] - e0[k] + 1) >> 1);
+    for (int k = 0; k < NV; ++k) steps = max(steps, (e1[k] - e0[k] + FPS - 1) / FPS);
     for (int g = 0; g < steps; ++g) {
-        int4 t[NV][2];
+        int4 t[NV][FPS];
 #pragma unroll
         for (int k = 0; k < NV; ++k)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) t[k][u] = reinterpret_cast<const int4*>(vf_tri)[max(min(e0[k] + 2 * g + u, e1[k] - 1), 0)];
-        float3 p[NV][2][3];
+            for (int u = 0; u < FPS; ++u) t[k][u] = reinterpret_cast<const int4*>(vf_tri)[max(min(e0[k] + FPS * g + u, e1[k] - 1), 0)];
+        float3 p[NV][FPS][3];
 #pragma unroll
         for (int k = 0; k < NV; ++k)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < FPS; ++u) {
                 p[k][u][0] = *reinterpret_cast<const float3*>(vb + (size_t)t[k][u].x * 3);
                 p[k][u][1] = *reinterpret_cast<const float3*>(vb + (size_t)t[k][u].y * 3);
                 p[k][u][2] = *reinterpret_cast<const float3*>(vb + (size_t)t[k][u].z * 3);
@@ -77,8 +77,8 @@ __device__ __forceinline__ void saga_vertex_normals_multi(const float* __restric
 #pragma unroll
         for (int k = 0; k < NV; ++k)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (e0[k] + 2 * g + u >= e1[k]) continue;
+            for (int u = 0; u < FPS; ++u) {
+                if (e0[k] + FPS * g + u >= e1[k]) continue;
                 const float ax = p[k][u][1].x - p[k][u][0].x, ay = p[k][u][1].y - p[k][u][0].y, az = p[k][u][1].z - p[k][u][0].z;
                 const float bx = p[k][u][2].x - p[k][u][0].x, by = p[k][u][2].y - p[k][u][0].y, bz = p[k][u][2].z - p[k][u][0].z;
                 n[k][0] += ay * bz - az * by;
