@@ -220,6 +220,7 @@ extern "C" int saga_debug_read_phases(unsigned long long* out) {
 // tile live in LDS in their own centred frames as (-2x,-2y,-2z,|p|^2); the approximate pass costs 3 fmas per pair, the
 // exact pass re-evaluates the two candidate chunks of every query with the arithmetic of nn_scan.h.
 #define GLF_NO 4                // object points per lane and pass, object -> hand
+#define GL_OPL (GL_TILE / GL_THREADS)   // object points per lane of the fast kernel (8)
 #ifndef GL_NRM_FPS
 #define GL_NRM_FPS 2             // faces per vertex and gather step of the hand normals (3: 1.22 ms against 1.10, registers)
 #endif
@@ -247,6 +248,11 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     const float* onb = obj_n + (size_t)b * O * 3;
     GL_T0();
 
+    // the lane's object points (O <= GL_TILE = GL_OPL * GL_THREADS): requested first, together with the query gathers below, and
+    // kept in registers for the bounding box AND the tile -- one trip to memory instead of two
+    float3 op[GL_OPL];
+#pragma unroll
+    for (int i = 0; i < GL_OPL; ++i) op[i] = *reinterpret_cast<const float3*>(ob + (size_t)min(tid + i * GL_THREADS, O - 1) * 3);
     // ---- x -> y queries: lane owns hand vertices / markers q = tid + i*GL_THREADS, i < GL_NQ ------------------
     float qx[GL_NQ], qy[GL_NQ], qz[GL_NQ];
     float hlo[3] = {INFINITY, INFINITY, INFINITY}, hhi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -268,9 +274,22 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     }
     GL_T(0);
     // frames of the two clouds (block-wide bounding boxes) and the two tiles
-    const NnfFrame fo = nnf_frame(ob, O, sbox, tid, GL_THREADS);
+    float olo[3] = {INFINITY, INFINITY, INFINITY}, ohi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int i = 0; i < GL_OPL; ++i) {      // (a clamped duplicate of point O - 1 does not change the box)
+        olo[0] = fminf(olo[0], op[i].x); ohi[0] = fmaxf(ohi[0], op[i].x);
+        olo[1] = fminf(olo[1], op[i].y); ohi[1] = fmaxf(ohi[1], op[i].y);
+        olo[2] = fminf(olo[2], op[i].z); ohi[2] = fmaxf(ohi[2], op[i].z);
+    }
+    const NnfFrame fo = nnf_frame_from_box(olo, ohi, sbox, tid, GL_THREADS);
     const NnfFrame fh = nnf_frame_from_box(hlo, hhi, sbox, tid, GL_THREADS);
-    const int Opad = nnf_stage_tile(sObj, ob, O, fo, tid, GL_THREADS);
+    const int Opad = (O + NNF_CH - 1) / NNF_CH * NNF_CH;
+#pragma unroll
+    for (int i = 0; i < GL_OPL; ++i) {
+        const int k = tid + i * GL_THREADS;
+        if (k < O) nnf_store_point(sObj, k, op[i].x, op[i].y, op[i].z, fo);
+        else if (k < Opad) nnf_store_point(sObj, k, NN_FAR, NN_FAR, NN_FAR, fo);
+    }
 #pragma unroll
     for (int i = 0; i < GL_NQ; ++i) {
         const int q = tid + i * GL_THREADS;
