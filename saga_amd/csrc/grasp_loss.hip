@@ -384,6 +384,16 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
             dst[0] = nr[r][0]; dst[1] = nr[r][1]; dst[2] = nr[r][2];
         }
     }
+    // The hand tile is scanned once per pass below by every wave: its A operands (matrix-core pass, nn_fast.h) are built once
+    // per block into the rest of the LDS space the object tile no longer needs (1 KB per 32 hand vertices, after the normals),
+    // with one scale for the whole block: every object point is within fo.rp of the object frame's centre.
+    const int h_tiles = (Hpad / NNF_CH + 1) >> 1;
+    float* sAimg = sNrm + ((H * 3 + 3) & ~3);
+    const bool a_image = (size_t)(((H * 3 + 3) & ~3) + h_tiles * 256) * sizeof(float) <= sizeof(sObj);
+    const NnfScales kh = nnf_scales(fh.rp, fo.rp * 1.0001f + fmaxf(fabsf(fo.cx - fh.cx), fmaxf(fabsf(fo.cy - fh.cy), fabsf(fo.cz - fh.cz))));
+    if (a_image)
+        for (int t = tid >> 6; t < h_tiles; t += GL_THREADS / 64)
+            reinterpret_cast<nn_h8*>(sAimg)[t * 64 + (tid & 63)] = nnf_build_A(sHand, Hpad, t, tid & 63, kh);
     __syncthreads();
 
     GL_T(5);
@@ -397,7 +407,8 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
             ox[i] = ob[k * 3]; oy[i] = ob[k * 3 + 1]; oz[i] = ob[k * 3 + 2];
             cx[i] = ox[i] - fh.cx; cy[i] = oy[i] - fh.cy; cz[i] = oz[i] - fh.cz;
         }
-        nnf_scan_mfma<GLF_NO>(sHand, Hpad / NNF_CH, fh, cx, cy, cz, m1, m2, m3, c1, c2);
+        if (a_image) nnf_scan_mfma_core<GLF_NO, true>(sAimg, Hpad / NNF_CH, kh, cx, cy, cz, m1, m2, m3, c1, c2);
+        else nnf_scan_mfma_core<GLF_NO, false>(sHand, Hpad / NNF_CH, kh, cx, cy, cz, m1, m2, m3, c1, c2);
 #pragma unroll
         for (int i = 0; i < GLF_NO; ++i) { best[i] = INFINITY; bj[i] = 0; }
         nnf_resolve<GLF_NO, true>(sHand, Hpad / NNF_CH, fh, 0, cx, cy, cz, ox, oy, oz, m1, m2, m3, c1, c2, best, bj);

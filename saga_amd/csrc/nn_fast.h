@@ -232,19 +232,50 @@ __device__ __forceinline__ void nnf_split16(float x, _Float16& hi, _Float16& lo)
     lo = (_Float16)(x - (float)hi);
 }
 
-template <int NQ>
-__device__ __forceinline__ void nnf_scan_mfma(const float* __restrict__ s, int n_chunks, const NnfFrame& f, const float (&qx)[NQ],
-                                              const float (&qy)[NQ], const float (&qz)[NQ], float (&m1)[NQ], float (&m2)[NQ],
-                                              float (&m3)[NQ], int (&c1)[NQ], int (&c2)[NQ]) {
+// scales (powers of two) of the matrix-core pass: 2 Rp sa in [128, 256); max|q| sq < 256 and Rp sq < 256, so that
+// w = |p|^2 sa sq < 32768.  rq: any upper bound of the framed queries' largest |coordinate| the pass will see.
+struct NnfScales { float sa, sq, S, inv_S; };
+__device__ __forceinline__ NnfScales nnf_scales(float rp, float rq) {
+    NnfScales k;
+    k.sa = nnf_pow2_scale(2.f * rp);
+    k.sq = fminf(nnf_pow2_scale(rq), nnf_pow2_scale(rp));
+    k.S = k.sa * k.sq;
+    k.inv_S = 1.f / k.S;
+    return k;
+}
+
+// A operand of this lane for 32-point tile `tile` of the framed f32 tile s (n_pts points, a multiple of NNF_CH)
+__device__ __forceinline__ nn_h8 nnf_build_A(const float* __restrict__ s, int n_pts, int tile, int lane, const NnfScales& k) {
+    const int col = lane & 31, h = lane >> 5;
+    const int prow = 16 * ((col >> 2) & 1) + 4 * (col >> 3) + (col & 3);      // point of the tile this lane's A row carries
+    const _Float16 big = (_Float16)65504.f, hz = (_Float16)0.f;
+    const int p = min(tile * 32 + prow, n_pts - 1);
+    const float* d = s + (p >> 4) * NNF_CSTRIDE + ((p & 15) >> 1) * 8 + (p & 1);
+    const float X = d[0], Y = d[2], Z = d[4], W = d[6];
+    const bool pad = !(fabsf(X) < 1.0e17f);
+    _Float16 axh, axl, ayh, ayl, azh, azl, wh, wm, wl;
+    nnf_split16(pad ? 0.f : X * k.sa, axh, axl);
+    nnf_split16(pad ? 0.f : Y * k.sa, ayh, ayl);
+    nnf_split16(pad ? 0.f : Z * k.sa, azh, azl);
+    const float w = pad ? 0.f : W * k.S;
+    wh = (_Float16)w;
+    const float r1 = w - (float)wh;
+    wm = (_Float16)r1;
+    wl = (_Float16)(r1 - (float)wm);
+    if (pad) { wh = big; wm = big; wl = big; }
+    const nn_h8 alo = {axh, ayh, azh, axh, ayh, azh, axl, ayl}, ahi = {azl, wh, wm, wl, axl, ayl, azl, pad ? big : hz};
+    return h ? ahi : alo;
+}
+
+// The scan proper.  IMAGE = false: s is the framed f32 tile, every wave builds its A operands as it goes.  IMAGE = true: s is
+// an LDS image of the A operands ([tile][lane] nn_h8, built once per block with nnf_build_A and THESE scales) -- for callers
+// that scan the same tile several times and have the LDS for it.
+template <int NQ, bool IMAGE>
+__device__ __forceinline__ void nnf_scan_mfma_core(const float* __restrict__ s, int n_chunks, const NnfScales& k, const float (&qx)[NQ],
+                                                   const float (&qy)[NQ], const float (&qz)[NQ], float (&m1)[NQ], float (&m2)[NQ],
+                                                   float (&m3)[NQ], int (&c1)[NQ], int (&c2)[NQ]) {
     const int lane = __lane_id(), col = lane & 31, h = lane >> 5;
-    // scales (powers of two): 2 Rp sa in [128, 256); max|q| sq < 256 and Rp sq < 256, so that w = |p|^2 sa sq < 32768
-    float rq = 0.f;
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) rq = fmaxf(rq, fmaxf(fabsf(qx[i]), fmaxf(fabsf(qy[i]), fabsf(qz[i]))));
-    for (int o = 32; o > 0; o >>= 1) rq = fmaxf(rq, __shfl_xor(rq, o, 64));
-    const float sa = nnf_pow2_scale(2.f * f.rp);
-    const float sq = fminf(nnf_pow2_scale(rq), nnf_pow2_scale(f.rp));
-    const float S = sa * sq, inv_S = 1.f / S;
+    const float sq = k.sq, inv_S = k.inv_S;
     // B operands: tile (i, hh) = query i of lanes hh*32 .. hh*32+31
     nn_h8 Bq[NQ][2];
     const _Float16 one = (_Float16)1.f;
@@ -268,29 +299,9 @@ __device__ __forceinline__ void nnf_scan_mfma(const float* __restrict__ s, int n
         for (int hh = 0; hh < 2; ++hh) { M1[i][hh] = INFINITY; M2[i][hh] = INFINITY; M3[i][hh] = INFINITY; C1[i][hh] = -1; C2[i][hh] = -1; }
 
     const int n_pts = n_chunks * NNF_CH, n_tiles = (n_chunks + 1) >> 1;
-    const int prow = 16 * ((col >> 2) & 1) + 4 * (col >> 3) + (col & 3);      // point of the tile this lane's A row carries
     const nn_f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const _Float16 big = (_Float16)65504.f, hz = (_Float16)0.f;
-    auto build_A = [&](int tile) -> nn_h8 {
-        const int p = min(tile * 32 + prow, n_pts - 1);
-        const float* d = s + (p >> 4) * NNF_CSTRIDE + ((p & 15) >> 1) * 8 + (p & 1);
-        const float X = d[0], Y = d[2], Z = d[4], W = d[6];
-        const bool pad = !(fabsf(X) < 1.0e17f);
-        _Float16 axh, axl, ayh, ayl, azh, azl, wh, wm, wl;
-        nnf_split16(pad ? 0.f : X * sa, axh, axl);
-        nnf_split16(pad ? 0.f : Y * sa, ayh, ayl);
-        nnf_split16(pad ? 0.f : Z * sa, azh, azl);
-        const float w = pad ? 0.f : W * S;
-        wh = (_Float16)w;
-        const float r1 = w - (float)wh;
-        wm = (_Float16)r1;
-        wl = (_Float16)(r1 - (float)wm);
-        if (pad) { wh = big; wm = big; wl = big; }
-        const nn_h8 alo = {axh, ayh, azh, axh, ayh, azh, axl, ayl}, ahi = {azl, wh, wm, wl, axl, ayl, azl, pad ? big : hz};
-        return h ? ahi : alo;
-    };
     for (int tile = 0; tile < n_tiles; ++tile) {
-        const nn_h8 A = build_A(tile);
+        const nn_h8 A = IMAGE ? reinterpret_cast<const nn_h8*>(s)[tile * 64 + lane] : nnf_build_A(s, n_pts, tile, lane, k);
         const int c = 2 * tile + h;
         const bool valid = c < n_chunks;
 #pragma unroll
@@ -325,6 +336,19 @@ __device__ __forceinline__ void nnf_scan_mfma(const float* __restrict__ s, int n
         nnf_insert3(b3, -1, a1, a2, a3, k1, k2);       // only its value can matter (as m3)
         m1[i] = a1 * inv_S; m2[i] = a2 * inv_S; m3[i] = a3 * inv_S; c1[i] = k1; c2[i] = k2;
     }
+}
+
+// Stand-alone form: scales from this wave's own queries, A operands built on the fly.
+template <int NQ>
+__device__ __forceinline__ void nnf_scan_mfma(const float* __restrict__ s, int n_chunks, const NnfFrame& f, const float (&qx)[NQ],
+                                              const float (&qy)[NQ], const float (&qz)[NQ], float (&m1)[NQ], float (&m2)[NQ],
+                                              float (&m3)[NQ], int (&c1)[NQ], int (&c2)[NQ]) {
+    float rq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) rq = fmaxf(rq, fmaxf(fabsf(qx[i]), fmaxf(fabsf(qy[i]), fabsf(qz[i]))));
+    for (int o = 32; o > 0; o >>= 1) rq = fmaxf(rq, __shfl_xor(rq, o, 64));
+    const NnfScales k = nnf_scales(f.rp, rq);
+    nnf_scan_mfma_core<NQ, false>(s, n_chunks, k, qx, qy, qz, m1, m2, m3, c1, c2);
 }
 
 // exact evaluation of one chunk for one query (original coordinates o*), index order, strict '<'.  Two points per packed
