@@ -252,7 +252,11 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     // kept in registers for the bounding box AND the tile -- one trip to memory instead of two
     float3 op[GL_OPL];
 #pragma unroll
-    for (int i = 0; i < GL_OPL; ++i) op[i] = *reinterpret_cast<const float3*>(ob + (size_t)min(tid + i * GL_THREADS, O - 1) * 3);
+    for (int i = 0; i < GL_OPL; ++i) {
+        typedef float f32x3_t __attribute__((ext_vector_type(3)));
+        const f32x3_t t = __builtin_nontemporal_load(reinterpret_cast<const f32x3_t*>(ob + (size_t)min(tid + i * GL_THREADS, O - 1) * 3));
+        op[i] = make_float3(t.x, t.y, t.z);
+    }
     // ---- x -> y queries: lane owns hand vertices / markers q = tid + i*GL_THREADS, i < GL_NQ ------------------
     float qx[GL_NQ], qy[GL_NQ], qz[GL_NQ];
     float hlo[3] = {INFINITY, INFINITY, INFINITY}, hhi[3] = {-INFINITY, -INFINITY, -INFINITY};

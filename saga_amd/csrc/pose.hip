@@ -217,8 +217,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void pose_bwd_kernel(
         // (lane owns columns 4*lane..+3 and 256+4*lane..+3); every lane then picks its 9 columns from LDS
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
         for (int s = 0; s < n_slabs; ++s) {
-            const float4* row = reinterpret_cast<const float4*>(slabs + ((size_t)s * B + b) * FEAT_K);
-            const float4 u = row[lane], v = row[64 + lane];
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            const f32x4_t* row = reinterpret_cast<const f32x4_t*>(slabs + ((size_t)s * B + b) * FEAT_K);
+            const f32x4_t u = __builtin_nontemporal_load(row + lane), v = __builtin_nontemporal_load(row + 64 + lane);   // read once
             a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
             a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
         }
