@@ -188,3 +188,25 @@ def test_fitting_results_schema_matches_reference_driver(tmp_path):
     assert back['object'][()]['verts_object'].shape == (n, O, 3)
     assert back['contact'][()]['body'].shape == (n, 143) and back['contact'][()]['object'].shape == (n, O)
     assert list(back['gender']) == ['male'] * n and list(back['object_name']) == ['camera'] * n
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(local_weights=True), dict(weights_nnz=6), dict(dense_weights=True)])
+def test_synthetic_body_model_weight_tables(kw):
+    """The synthetic SMPL-X arrays and their weight-table variants: rows of the skinning weights sum to 1 with the
+    advertised number of non-zeros; the mesh-like variant gives runs of consecutive vertices the same joints."""
+    from saga_amd.synthetic import make_body_model
+    d = make_body_model(seed=5, n_verts=550, n_faces=1090, **kw)
+    w = d['weights'].astype(np.float64)
+    assert w.shape == (550, 55) and (w >= 0).all()
+    np.testing.assert_allclose(w.sum(1), 1.0, atol=1e-6)
+    nnz = (w != 0).sum(1)
+    if kw.get('dense_weights'):
+        assert nnz.min() > 40
+    else:
+        assert (nnz == kw.get('weights_nnz', 4)).all()
+    if kw.get('local_weights'):
+        first = np.argmax(w != 0, axis=1)
+        # 550 vertices over 55 joints: runs of 10 vertices share their joints (the wrap-around rows aside)
+        assert (np.diff(first[:500]) >= 0).all() and len(np.unique(first)) >= 50
+    assert d['f'].max() < 550 and np.unique(d['f']).size == 550          # every vertex is on a face
+    np.testing.assert_allclose(d['J_regressor'].sum(1), 1.0, atol=1e-5)
