@@ -293,6 +293,19 @@ int saga_fit_step(const saga_model_t* m, const saga_decoder_t* dec, const saga_g
                   float* vars, float* adam_m, float* adam_v, float* ws,
                   float* loss, float* loss_terms, float* markers_rec, int B, void* stream);
 
+/* The same iteration with a structurally sparse backward (no counterpart in the reference, whose autograd forms the dense
+ * [B,V,3] vertex gradient at fittingop.py:383).  The loss reads only the tables' `unique_ids` vertices (markers, right
+ * hand, feet: ~1,050 of 10,475), so the vertex gradient is zero everywhere else and the dense backward multiplies those
+ * zeros through the skinning transpose and the blend contraction.  Here the loss backward writes the compact gradient
+ * [B,n_unique,3] and the SMPL-X backward runs on `m_loss` = saga_model_create_subset(desc, unique_ids, n_unique) -- the
+ * forward still evaluates the whole mesh with `m`.  Same gradients as saga_fit_step up to the rounding of the shorter
+ * sums (the skipped terms are exact zeros); same workspace, same arguments otherwise.  "g_vertices" of
+ * saga_fit_workspace_offset is not written by this variant. */
+int saga_fit_step_sparse(const saga_model_t* m, const saga_model_t* m_loss, const saga_decoder_t* dec,
+                         const saga_grasp_tables_t* tb, const saga_fit_problem_t* prob, const saga_fit_step_cfg_t* cfg,
+                         float* vars, float* adam_m, float* adam_v, float* ws,
+                         float* loss, float* loss_terms, float* markers_rec, int B, void* stream);
+
 /* optimiser variables -> the SMPL-X parameter dict the reference saves (fittingop.py:466-475):
  * body_params [B,SAGA_BODY_PARAM_COUNT] */
 int saga_fit_decode(const saga_decoder_t* dec, const float* vars, float* body_params, float* ws, int B, void* stream);

@@ -109,6 +109,9 @@ PROTOTYPES = {
                                                       ctypes.c_char_p]),
     'saga_fit_step': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(GraspTables), ctypes.POINTER(FitProblem),
                                      ctypes.POINTER(FitStepCfg)] + [ctypes.c_void_p] * 7 + [ctypes.c_int, c_stream]),
+    'saga_fit_step_sparse': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(GraspTables),
+                                            ctypes.POINTER(FitProblem), ctypes.POINTER(FitStepCfg)] + [ctypes.c_void_p] * 7 +
+                             [ctypes.c_int, c_stream]),
     'saga_fit_decode': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_stream]),
     'saga_fit_best_update': (ctypes.c_int, [c_float_p] * 6 + [ctypes.c_int, ctypes.c_int, c_stream]),
     'saga_profile_enable': (ctypes.c_int, [ctypes.c_int]),

@@ -22,7 +22,7 @@ int saga_grasp_loss_bwd_tagged(const saga_model_t* m, const saga_grasp_tables_t*
                                const float* obj, const float* markers_target, const float* c_markers, const float* c_object,
                                const float* markers_rec, const float* hand_rec, const float* h2o_signed,
                                const float* o2h_signed, const int32_t* idx_m2o, const int32_t* idx_h2o,
-                               const int32_t* idx_o2h, float* g_verts, int B, int O, int32_t* zero_tag, int32_t tag, void* stream);
+                               const int32_t* idx_o2h, float* g_verts, int B, int O, int32_t* zero_tag, int32_t tag, int compact, void* stream);
 int saga_launch_gemm_nt(int epi, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, const float* bias,
                         const float* aux, int M, int N, int K, hipStream_t st);
 
@@ -350,6 +350,24 @@ __global__ __launch_bounds__(PK_THREADS) void best_update_kernel(const float* __
     if (tid == 0) best_loss[b] = l;
 }
 
+// v_posed rows of the vertices a subset model keeps, laid out as that model expects them ([B, Npad_s], pad columns 0):
+// four columns per thread, one block row per candidate
+__global__ __launch_bounds__(256) void gather_v_posed_kernel(const float* __restrict__ v_posed, int npad, const int32_t* __restrict__ sel,
+                                                             int n3, int npad_s, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c0 >= npad_s) return;
+    const float* src = v_posed + (size_t)b * npad;
+    float4 v;
+    float* pv = &v.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + k;
+        pv[k] = c < n3 ? src[sel[c / 3] * 3 + c % 3] : 0.f;
+    }
+    *reinterpret_cast<float4*>(out + (size_t)b * npad_s + c0) = v;
+}
+
 // ---- host orchestration ------------------------------------------------------------------------------------------
 struct Prof {
     void* p;
@@ -391,9 +409,10 @@ extern "C" int saga_fit_best_update(const float* loss, const float* vars, const 
     return 0;
 }
 
-extern "C" int saga_fit_step(const saga_model_t* m, const saga_decoder_t* d, const saga_grasp_tables_t* tb,
-                             const saga_fit_problem_t* prob, const saga_fit_step_cfg_t* cfg, float* vars, float* adam_m,
-                             float* adam_v, float* ws, float* loss, float* loss_terms, float* markers_rec, int B, void* stream) {
+// mb: NULL (dense backward over the whole mesh) or the subset model over tb->unique_ids (structurally sparse backward)
+static int fit_step_impl(const saga_model_t* m, const saga_model_t* mb, const saga_decoder_t* d, const saga_grasp_tables_t* tb,
+                         const saga_fit_problem_t* prob, const saga_fit_step_cfg_t* cfg, float* vars, float* adam_m,
+                         float* adam_v, float* ws, float* loss, float* loss_terms, float* markers_rec, int B, void* stream) {
     SAGA_CHECK_ARG(m && d && tb && prob && cfg && vars && adam_m && adam_v && ws && loss && markers_rec,
                    "saga_fit_step: null argument");
     SAGA_CHECK_ARG(B >= 0 && B <= 65535, "saga_fit_step: batch %d outside [0, 65535]", B);
@@ -403,6 +422,14 @@ extern "C" int saga_fit_step(const saga_model_t* m, const saga_decoder_t* d, con
                    cfg->stage, cfg->adam_step);
     SAGA_CHECK_ARG(prob->n_obj > 0 && prob->obj && prob->obj_normals && prob->markers_target && prob->c_markers && prob->c_object,
                    "saga_fit_step: incomplete problem");
+    if (mb) {
+        SAGA_CHECK_ARG(mb->sel_ids && mb->VF == m->V && mb->V == tb->n_unique && mb->S == m->S && !m->sel_ids,
+                       "saga_fit_step_sparse: the backward model must be the subset of the forward model's mesh over the tables' "
+                       "unique_ids (subset of %d vertices over a mesh of %d; tables list %d, mesh has %d)",
+                       mb->V, mb->VF, tb->n_unique, m->V);
+        SAGA_CHECK_ARG(2 * (size_t)mb->Npad + 3 * (size_t)mb->V <= (size_t)m->Npad,
+                       "saga_fit_step_sparse: %d loss vertices of %d leave no room for the compact buffers", mb->V, m->V);
+    }
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int O = prob->n_obj;
@@ -428,7 +455,29 @@ extern "C" int saga_fit_step(const saga_model_t* m, const saga_decoder_t* d, con
         loss_sum_kernel<<<(B + 127) / 128, 128, 0, st>>>(w.terms, vars, lc, w.g_terms, loss, loss_terms, B);
         SAGA_LAUNCH_CHECK();
     }
-    {
+    if (mb) {
+        // Structurally sparse backward: the loss reads only the tables' vertices, so g_vertices is zero everywhere else and
+        // every product the dense backward forms with those rows is an exact zero.  The loss backward writes the compact
+        // gradient [B,U,3], the forward's v_posed rows of those vertices are gathered, and the SMPL-X backward runs on the
+        // subset model (same joint regression, same chain; blend operand and weight tables of the U vertices only).  The
+        // three compact buffers live in the dense g_v_posed workspace (contents undefined between calls anyway).
+        float* gvp_s = w.gvp;
+        float* vps = gvp_s + (size_t)B * mb->Npad;
+        float* g_compact = vps + (size_t)B * mb->Npad;
+        if ((rc = saga_grasp_loss_bwd_tagged(m, tb, w.g_terms, w.verts, prob->obj, prob->markers_target, prob->c_markers,
+                                             prob->c_object, markers_rec, w.hand_rec, w.h2o_signed, w.o2h_signed, w.idx_m2o,
+                                             w.idx_h2o, w.idx_o2h, g_compact, B, O, nullptr, 0, 1, stream)))
+            return rc;
+        {
+            Prof p(SAGA_PROF_SKIN_BWD, stream);
+            dim3 grid((mb->Npad / 4 + 255) / 256, B);
+            gather_v_posed_kernel<<<grid, 256, 0, st>>>(w.v_posed, m->Npad, mb->sel_ids, mb->V * 3, mb->Npad, vps);
+            SAGA_LAUNCH_CHECK();
+        }
+        if ((rc = saga_smplx_bwd(mb, g_compact, nullptr, w.full_pose, w.rot, w.jrest, w.chain, w.A, vps, w.g_shape, w.g_pose,
+                                 w.g_transl, gvp_s, w.slab, w.dA, nullptr, B, stream)))
+            return rc;
+    } else {
         // the dense gradient rows of the workspace are zero-filled once: every call rewrites the same (tables') vertices.
         // The tag ties the "already zero" mark to this table set, mesh and workspace address; it is never 0, so a
         // zero-initialised workspace (the contract) always fills on first use.
@@ -438,12 +487,12 @@ extern "C" int saga_fit_step(const saga_model_t* m, const saga_decoder_t* d, con
         if (tag == 0) tag = 1;
         if ((rc = saga_grasp_loss_bwd_tagged(m, tb, w.g_terms, w.verts, prob->obj, prob->markers_target, prob->c_markers,
                                              prob->c_object, markers_rec, w.hand_rec, w.h2o_signed, w.o2h_signed, w.idx_m2o,
-                                             w.idx_h2o, w.idx_o2h, w.g_verts, B, O, w.zero_tag, tag, stream)))
+                                             w.idx_h2o, w.idx_o2h, w.g_verts, B, O, w.zero_tag, tag, 0, stream)))
+            return rc;
+        if ((rc = saga_smplx_bwd(m, w.g_verts, nullptr, w.full_pose, w.rot, w.jrest, w.chain, w.A, w.v_posed, w.g_shape, w.g_pose,
+                                 w.g_transl, w.gvp, w.slab, w.dA, nullptr, B, stream)))
             return rc;
     }
-    if ((rc = saga_smplx_bwd(m, w.g_verts, nullptr, w.full_pose, w.rot, w.jrest, w.chain, w.A, w.v_posed, w.g_shape, w.g_pose,
-                             w.g_transl, w.gvp, w.slab, w.dA, nullptr, B, stream)))
-        return rc;
     {
         Prof p(SAGA_PROF_PARAMS_BWD, stream);
         params_bwd_kernel<<<B, PK_THREADS, 0, st>>>(vars, w.jac, d->hand_comp, w.g_pose, w.g_shape, w.g_transl, w.grad, w.g_x6, m->S,
@@ -471,4 +520,18 @@ extern "C" int saga_fit_step(const saga_model_t* m, const saga_decoder_t* d, con
         SAGA_LAUNCH_CHECK();
     }
     return 0;
+}
+
+extern "C" int saga_fit_step(const saga_model_t* m, const saga_decoder_t* d, const saga_grasp_tables_t* tb,
+                             const saga_fit_problem_t* prob, const saga_fit_step_cfg_t* cfg, float* vars, float* adam_m,
+                             float* adam_v, float* ws, float* loss, float* loss_terms, float* markers_rec, int B, void* stream) {
+    return fit_step_impl(m, nullptr, d, tb, prob, cfg, vars, adam_m, adam_v, ws, loss, loss_terms, markers_rec, B, stream);
+}
+
+extern "C" int saga_fit_step_sparse(const saga_model_t* m, const saga_model_t* m_loss, const saga_decoder_t* d,
+                                    const saga_grasp_tables_t* tb, const saga_fit_problem_t* prob, const saga_fit_step_cfg_t* cfg,
+                                    float* vars, float* adam_m, float* adam_v, float* ws, float* loss, float* loss_terms,
+                                    float* markers_rec, int B, void* stream) {
+    SAGA_CHECK_ARG(m_loss, "saga_fit_step_sparse: null subset model");
+    return fit_step_impl(m, m_loss, d, tb, prob, cfg, vars, adam_m, adam_v, ws, loss, loss_terms, markers_rec, B, stream);
 }

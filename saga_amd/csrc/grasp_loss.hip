@@ -470,7 +470,9 @@ __global__ __launch_bounds__(GL_BWD_THREADS) void grasp_loss_bwd_kernel(
     const float* __restrict__ c_obj, const float* __restrict__ markers_rec, const float* __restrict__ hand_rec,
     const float* __restrict__ h2o_signed, const float* __restrict__ o2h_signed, const int32_t* __restrict__ idx_m2o,
     const int32_t* __restrict__ idx_h2o, const int32_t* __restrict__ idx_o2h, float* __restrict__ g_verts, int V, int O,
-    int32_t* __restrict__ zero_tag, int32_t tag) {
+    int32_t* __restrict__ zero_tag, int32_t tag, int compact) {
+    // compact: g_verts is [B, n_unique, 3] -- row i of a candidate is the gradient of vertex unique_ids[i] (what the
+    // structurally sparse backward of saga_fit_step_sparse consumes); nothing to zero-fill, every entry is written.
     // Accumulators are 64-bit fixed point (2^-40 units, range +-2^23): integer adds are associative, so the scatter-add of
     // many object points into one hand vertex gives the same bits whatever order the LDS atomics land in, and the sum is
     // the exactly rounded one (float atomics would make the whole iteration run-to-run irreproducible).
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(GL_BWD_THREADS) void grasp_loss_bwd_kernel(
     // float4 body, scalar tail; the scatter below comes after a barrier.  With a tag array (saga_fit_step's workspace,
     // which nobody else writes) the fill happens only the first time: every later call rewrites exactly the same
     // vertices (the tables' unique ids) and everything else is still zero.
-    if (!zero_tag || zero_tag[b] != tag) {
+    if (!compact && (!zero_tag || zero_tag[b] != tag)) {
         float* gb0 = g_verts + (size_t)b * V * 3;
         const int n = V * 3;
         const int head = min(n, (int)((16 - ((uintptr_t)gb0 & 15)) & 15) >> 2);
@@ -550,6 +552,11 @@ __global__ __launch_bounds__(GL_BWD_THREADS) void grasp_loss_bwd_kernel(
         }
     }
     __syncthreads();
+    if (compact) {
+        float* gc = g_verts + (size_t)b * U * 3;
+        for (int i = tid; i < U * 3; i += GL_BWD_THREADS) gc[i] = (float)((double)(long long)acc[i] * 9.094947017729282e-13);
+        return;
+    }
     float* gb = g_verts + (size_t)b * V * 3;
     for (int i = tid; i < U * 3; i += GL_BWD_THREADS) gb[tb.unique_ids[i / 3] * 3 + (i % 3)] = (float)((double)(long long)acc[i] * 9.094947017729282e-13);
     if (zero_tag && tid == 0) zero_tag[b] = tag;
@@ -598,12 +605,12 @@ extern "C" int saga_grasp_loss_fwd(const saga_model_t* m, const saga_grasp_table
     return 0;
 }
 
-// zero_tag (device int32 [B], may be NULL) / tag: see the kernel; used by saga_fit_step only
+// zero_tag (device int32 [B], may be NULL) / tag / compact: see the kernel; used by saga_fit_step[_sparse] only
 int saga_grasp_loss_bwd_tagged(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* g_terms, const float* verts,
                                const float* obj, const float* markers_target, const float* c_markers, const float* c_object,
                                const float* markers_rec, const float* hand_rec, const float* h2o_signed,
                                const float* o2h_signed, const int32_t* idx_m2o, const int32_t* idx_h2o,
-                               const int32_t* idx_o2h, float* g_verts, int B, int O, int32_t* zero_tag, int32_t tag, void* stream);
+                               const int32_t* idx_o2h, float* g_verts, int B, int O, int32_t* zero_tag, int32_t tag, int compact, void* stream);
 
 extern "C" int saga_grasp_loss_bwd(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* g_terms, const float* verts,
                                    const float* obj, const float* markers_target, const float* c_markers, const float* c_object,
@@ -611,14 +618,14 @@ extern "C" int saga_grasp_loss_bwd(const saga_model_t* m, const saga_grasp_table
                                    const float* o2h_signed, const int32_t* idx_m2o, const int32_t* idx_h2o,
                                    const int32_t* idx_o2h, float* g_verts, int B, int O, void* stream) {
     return saga_grasp_loss_bwd_tagged(m, tb, g_terms, verts, obj, markers_target, c_markers, c_object, markers_rec, hand_rec, h2o_signed,
-                                      o2h_signed, idx_m2o, idx_h2o, idx_o2h, g_verts, B, O, nullptr, 0, stream);
+                                      o2h_signed, idx_m2o, idx_h2o, idx_o2h, g_verts, B, O, nullptr, 0, 0, stream);
 }
 
 int saga_grasp_loss_bwd_tagged(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* g_terms, const float* verts,
                                const float* obj, const float* markers_target, const float* c_markers, const float* c_object,
                                const float* markers_rec, const float* hand_rec, const float* h2o_signed,
                                const float* o2h_signed, const int32_t* idx_m2o, const int32_t* idx_h2o,
-                               const int32_t* idx_o2h, float* g_verts, int B, int O, int32_t* zero_tag, int32_t tag, void* stream) {
+                               const int32_t* idx_o2h, float* g_verts, int B, int O, int32_t* zero_tag, int32_t tag, int compact, void* stream) {
     SAGA_CHECK_ARG(m, "saga_grasp_loss_bwd: null model");
     int rc = check_tables(tb);
     if (rc) return rc;
@@ -632,7 +639,7 @@ int saga_grasp_loss_bwd_tagged(const saga_model_t* m, const saga_grasp_tables_t*
     hipError_t e = hipSuccess;
     grasp_loss_bwd_kernel<<<B, GL_BWD_THREADS, 0, st>>>(*tb, g_terms, verts, obj, markers_target, c_markers, c_object, markers_rec,
                                                         hand_rec, h2o_signed, o2h_signed, idx_m2o, idx_h2o, idx_o2h, g_verts, m->V, O,
-                                                        zero_tag, tag);
+                                                        zero_tag, tag, compact);
     saga_prof_end(prof);
     SAGA_HIP(e);
     SAGA_LAUNCH_CHECK();

@@ -31,7 +31,7 @@ extern "C" void saga_model_destroy(saga_model_t* m) {
     if (!m) return;
     void* ptrs[] = {m->Bt, m->Bk, m->v_template, m->J_template, m->J_dirs, m->parents, m->depth, m->child_ptr,
                     m->child_idx, m->w_idx, m->w_val, m->Wd, m->ds_ent, m->ds_meta, m->ds_item_ptr, m->faces, m->vf_ptr, m->vf_idx, m->vf_tri, m->lmk_verts,
-                    m->lmk_bary, m->extra_verts};
+                    m->lmk_bary, m->extra_verts, m->sel_ids};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -91,8 +91,13 @@ static int model_create_impl(saga_model_t** out, const saga_model_desc_t* d, con
     m->Npad = saga_roundup(3 * V, SAGA_N_ALIGN);
     m->Vpad4 = saga_roundup(V, 256);
     m->device = dev;
+    m->VF = VF;
     const int N = m->N, Npad = m->Npad;
     int rc = 0;
+    if (sel) {
+        std::vector<int32_t> ids(sel, sel + n_sel);
+        if ((rc = upload(&m->sel_ids, ids))) goto fail;
+    }
 
     {   // blend operands, both orientations
         std::vector<float> Bt((size_t)Npad * FEAT_K, 0.f), Bk((size_t)FEAT_K * Npad, 0.f), vt(Npad, 0.f);

@@ -88,6 +88,10 @@ struct saga_model {
     int32_t* lmk_verts; // [L,3] vertex ids of each landmark's triangle
     float*   lmk_bary;  // [L,3]
     int32_t* extra_verts; // [E]
+    // vertex subset (saga_model_create_subset): VF = vertices of the full mesh, sel_ids [V] = full-mesh id of every kept vertex
+    // (ascending); a full model has VF = V and sel_ids = NULL
+    int VF;
+    int32_t* sel_ids;
 };
 
 static inline int saga_roundup(int x, int m) { return (x + m - 1) / m * m; }

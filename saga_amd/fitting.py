@@ -62,14 +62,17 @@ class FittingOP:
     ``smplx_kwargs`` (extra ``smplx.create`` kwargs, e.g. ``vertex_ids`` for reduced test meshes),
     ``genders`` (which models to create; default both like the reference), ``native`` (default True: ``fitting``
     drives ``saga_fit_step`` -- the whole iteration incl. Adam as one kernel sequence; False: PyTorch autograd over
-    the drop-in operators + ``torch.optim.Adam``, the form the reference has), ``record_history``."""
+    the drop-in operators + ``torch.optim.Adam``, the form the reference has), ``record_history``, ``sparse_backward``
+    (native path only, default False: ``saga_fit_step_sparse`` -- the backward runs over the ~1,050 vertices the loss reads
+    instead of multiplying the structural zeros of the dense [B,V,3] vertex gradient through the whole mesh; the forward
+    is unchanged and the gradients agree to rounding)."""
 
     def __init__(self, fittingconfig):
         cfg = dict(init_lr_h=0.008, num_iter=[300, 400, 500], batch_size=1, num_markers=143, device='cuda',
                    verbose=False, hand_ncomps=24, only_rec=False, contact_loss='contact', logger=print,
                    data_type='markers_143', body_model_path='./body_utils/body_models', vposer=None, indices=None,
                    smplx_kwargs={}, genders=('male', 'female'), fused=True, native=True,
-                   record_history=True, loss_vertices_only=False)
+                   record_history=True, loss_vertices_only=False, sparse_backward=False)
         cfg.update(fittingconfig)
         for key, val in cfg.items():
             setattr(self, key, val)
@@ -363,10 +366,14 @@ class FittingOP:
         cfg = _lib.FitStepCfg(ss, int(bool(self.only_rec)), int(self.contact_loss == 'prior'), o['mask'], o['step'],
                               o['lr'], 0.9, 0.999, 1e-8)
         P = _lib.ptr
-        _lib.check(_lib.load().saga_fit_step(
-            self.bm.handle(self.device), self._native_handles(), ctypes.byref(self.tables.struct), ctypes.byref(problem['struct']),
-            ctypes.byref(cfg), P(self.vars), P(o['m']), P(o['v']), P(self._workspace(problem['struct'].n_obj)), P(problem['loss']),
-            P(loss_terms), P(problem['markers_rec']), self.batch_size, _lib.stream()), 'saga_fit_step')
+        rest = (self._native_handles(), ctypes.byref(self.tables.struct), ctypes.byref(problem['struct']),
+                ctypes.byref(cfg), P(self.vars), P(o['m']), P(o['v']), P(self._workspace(problem['struct'].n_obj)), P(problem['loss']),
+                P(loss_terms), P(problem['markers_rec']), self.batch_size, _lib.stream())
+        if self.sparse_backward:
+            m_loss = self.bm.subset_handle(self.device, self.tables.unique_ids_host)
+            _lib.check(_lib.load().saga_fit_step_sparse(self.bm.handle(self.device), m_loss, *rest), 'saga_fit_step_sparse')
+        else:
+            _lib.check(_lib.load().saga_fit_step(self.bm.handle(self.device), *rest), 'saga_fit_step')
         return problem['loss'], problem['markers_rec']
 
     def workspace_view(self, name, n_obj, shape, dtype=torch.float32):

@@ -26,6 +26,7 @@ class GraspTables:
         i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=device)
         self.marker_ids, self.hand_ids, self.foot_ids = i32(markers), i32(hand), i32(foot)
         self.unique_ids = i32(uniq)
+        self.unique_ids_host = np.ascontiguousarray(uniq, dtype=np.int32)
         self.marker_slot, self.hand_slot, self.foot_slot = i32(slot(markers)), i32(slot(hand)), i32(slot(foot))
         self.hand_weights = torch.as_tensor(np.asarray(hand_weights), dtype=torch.float32, device=device).contiguous()
         self.n_markers, self.n_hand, self.n_foot, self.n_unique = len(markers), len(hand), len(foot), len(uniq)

@@ -192,6 +192,33 @@ class SMPLX(nn.Module):
             self._handles[idx] = h
         return h
 
+    def subset_handle(self, device, vertex_ids):
+        """``saga_model_t*`` of this (full) model restricted to ``vertex_ids`` (ascending, unique) on ``device``: the model
+        ``saga_fit_step_sparse`` runs its backward on.  Cached per device and id list, freed with the module."""
+        if self.vertex_subset is not None:
+            raise RuntimeError('subset_handle: this module already evaluates a vertex subset')
+        ids = np.ascontiguousarray(vertex_ids, dtype=np.int32)
+        if ids.ndim != 1 or ids.size == 0 or np.any(np.diff(ids) <= 0) or ids[0] < 0 or ids[-1] >= self.num_verts:
+            raise ValueError('subset_handle: vertex ids must be ascending, unique and inside the mesh')
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        key = ('subset', idx, ids.tobytes())
+        h = self._handles.get(key)
+        if h is None:
+            hp = self._host
+            p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+            desc = _lib.ModelDesc(
+                n_verts=hp['v_template'].shape[0], n_shape=self.num_shape, n_faces=hp['faces'].shape[0], n_landmarks=0,
+                n_extra_joints=0, v_template_host=p(hp['v_template']), shapedirs_host=p(hp['shapedirs']),
+                posedirs_host=p(hp['posedirs']), J_regressor_host=p(hp['J_regressor']), parents_host=p(hp['parents']),
+                lbs_weights_host=p(hp['weights']), faces_host=p(hp['faces']), lmk_faces_idx_host=None, lmk_bary_host=None,
+                extra_joint_verts_host=None)
+            h = ctypes.c_void_p()
+            with torch.cuda.device(idx):
+                _lib.check(_lib.load().saga_model_create_subset(ctypes.byref(h), ctypes.byref(desc), p(ids), int(ids.size)),
+                           'saga_model_create_subset')
+            self._handles[key] = h
+        return h
+
     def npad(self, device):
         return _lib.load().saga_model_npad(self.handle(device))
 
