@@ -55,12 +55,16 @@ def convert_to_3D_rot(x):
     return torch.cat([x[:, :3], cont6d_to_aa(x[:, 3:9]), x[:, 9:]], dim=-1)
 
 
-def gen_body_mesh_v1(body_params, smplx_model, vposer_model):
-    """``utils/utils_body.py:93-106``: [N, 3+3+10+32+24+24] -> (vertices [N,V,3], SMPL-X keyword dict)."""
+def gen_body_mesh_v1(body_params, smplx_model, vposer_model, vertex_grad_ids=None):
+    """``utils/utils_body.py:93-106``: [N, 3+3+10+32+24+24] -> (vertices [N,V,3], SMPL-X keyword dict).  With
+    ``vertex_grad_ids`` -> ((vertices without gradient, vertices[:, ids] with gradient), dict)."""
     bs = body_params.shape[0]
     d = {'transl': body_params[:, 0:3], 'global_orient': body_params[:, 3:6], 'betas': body_params[:, 6:16],
          'body_pose': vposer_model.decode(body_params[:, 16:48], output_type='aa').view(bs, -1),
          'left_hand_pose': body_params[:, 48:72], 'right_hand_pose': body_params[:, 72:]}
+    if vertex_grad_ids is not None:
+        out = smplx_model(return_verts=True, vertex_grad_ids=vertex_grad_ids, **d)
+        return (out.vertices, out.vertices_sel), d
     return smplx_model(return_verts=True, **d).vertices, d
 
 
@@ -68,12 +72,15 @@ class FittingOP:
     """``FittingOP(fittingconfig)`` with the reference's keys (``opt_graspmotion.py:470-495``): T, gender, smplx_beta,
     init_lr_stage1/2, num_iter, device, markers_ids, markers_ids_143, stage1_weight_loss_*, stage2_weight_loss_*.
     Additional optional keys: ``n_seq`` (S; ``smplx_beta`` is then [S,10]), ``start_t`` (30), ``body_model_path``,
-    ``vposer``, ``smplx_kwargs``, ``indices`` (foot groups), ``body_smooth_loss`` (see the module docstring)."""
+    ``vposer``, ``smplx_kwargs``, ``indices`` (foot groups), ``body_smooth_loss`` (see the module docstring),
+    ``sparse_backward`` (default True: stage 2 differentiates through the vertices its losses read only -- same gradients up
+    to summation order, no dense [S*T,V,3] gradient; switched off automatically with a ``body_smooth_loss`` hook, which may
+    read any vertex)."""
 
     def __init__(self, fittingconfig):
         cfg = dict(T=61, gender='male', device='cuda', n_seq=1, start_t=30, init_lr_stage1=0.1, init_lr_stage2=0.01,
                    num_iter=[100, 300], body_model_path='./body_utils/body_models', vposer=None, smplx_kwargs={},
-                   indices=None, body_smooth_loss=None,
+                   indices=None, body_smooth_loss=None, sparse_backward=True,
                    stage1_weight_loss_rec_markers=1.0, stage1_weight_loss_vposer=0.02, stage1_weight_loss_shape=0.01,
                    stage1_weight_loss_hand=0.01,
                    stage2_weight_loss_rec_markers=0.1, stage2_weight_loss_end_markers_fit=10, stage2_weight_loss_vposer=0.02,
@@ -187,12 +194,18 @@ class FittingOP:
         S, T, start_t, w = self.n_seq, self.T, self.start_t, self
         p = convert_to_3D_rot(torch.cat([self.transl_opt_T, self.rot_6d_opt_T, self.shape_T, self.other_params_opt_T],
                                         dim=-1).reshape(S * T, -1))
-        verts, _ = gen_body_mesh_v1(p, self.smplx_model_batch, self.vposer_model)
-        verts = verts.reshape(S, T, -1, 3)
         if self._picker is None:
             self._make_picker(rhand_verts)
         pk = self._picker
-        sub = pk.gather(verts)                                   # every vertex any term reads, gathered once
+        if self.sparse_backward and self.body_smooth_loss is None:
+            # every vertex any term reads, as the differentiable output: the backward runs over those ~1,100 vertices only
+            # (the full mesh is still evaluated -- the normals read it -- but carries no gradient)
+            (verts, sub), _ = gen_body_mesh_v1(p, self.smplx_model_batch, self.vposer_model, vertex_grad_ids=pk.union)
+            verts, sub = verts.reshape(S, T, -1, 3), sub.reshape(S, T, -1, 3)
+        else:
+            verts, _ = gen_body_mesh_v1(p, self.smplx_model_batch, self.vposer_model)
+            verts = verts.reshape(S, T, -1, 3)
+            sub = pk.gather(verts)                               # every vertex any term reads, gathered once
         markers = sub.index_select(2, pk.pos['markers'])
         mask = torch.ones(1, 1, markers.shape[2], 1, device=self.device)
         mask[:, :, 49:49 + 6] = 0        # hand

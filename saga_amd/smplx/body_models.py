@@ -36,7 +36,7 @@ _EXTRA_ORDER = ['nose', 'reye', 'leye', 'rear', 'lear', 'LBigToe', 'LSmallToe', 
                 'RHeel', 'lthumb', 'lindex', 'lmiddle', 'lring', 'lpinky', 'rthumb', 'rindex', 'rmiddle', 'rring', 'rpinky']
 
 _OUT_FIELDS = ['vertices', 'joints', 'full_pose', 'global_orient', 'transl', 'v_shaped', 'betas', 'body_pose',
-               'expression', 'left_hand_pose', 'right_hand_pose', 'jaw_pose']
+               'expression', 'left_hand_pose', 'right_hand_pose', 'jaw_pose', 'vertices_sel']
 SMPLXOutput = namedtuple('SMPLXOutput', _OUT_FIELDS, defaults=[None] * len(_OUT_FIELDS))
 
 
@@ -219,6 +219,20 @@ class SMPLX(nn.Module):
             self._handles[key] = h
         return h
 
+    def _grad_subset(self, ids, device):
+        """(ids as a long tensor on ``device``, subset model handle) for ``forward(vertex_grad_ids=ids)``; cached by the
+        identity of ``ids`` (the entry keeps it alive), so the host copy is made once."""
+        cache = self.__dict__.setdefault('_grad_subsets', {})
+        key = (id(ids), str(device))
+        hit = cache.get(key)
+        if hit is None:
+            host = np.asarray(ids.detach().cpu().numpy() if torch.is_tensor(ids) else ids, dtype=np.int64).reshape(-1)
+            sel = torch.as_tensor(host, dtype=torch.long, device=device)
+            if len(cache) >= 8:
+                cache.clear()
+            hit = cache[key] = (ids, sel, self.subset_handle(device, host))
+        return hit[1], hit[2]
+
     def npad(self, device):
         return _lib.load().saga_model_npad(self.handle(device))
 
@@ -240,7 +254,11 @@ class SMPLX(nn.Module):
     # ---- forward ------------------------------------------------------------------------------------
     def forward(self, betas=None, global_orient=None, body_pose=None, left_hand_pose=None, right_hand_pose=None,
                 transl=None, expression=None, jaw_pose=None, leye_pose=None, reye_pose=None, return_verts=True,
-                return_full_pose=False, pose2rot=True, return_shaped=True, **kwargs):
+                return_full_pose=False, pose2rot=True, return_shaped=True, vertex_grad_ids=None, **kwargs):
+        """``vertex_grad_ids`` (not in smplx): ascending unique vertex ids (long tensor; pass the SAME tensor object every
+        call -- its subset model is cached by identity).  The output then carries ``vertices_sel`` = ``vertices[:, ids]``
+        and ONLY that tensor is differentiable: ``vertices`` and ``joints`` are returned without gradient.  For losses that
+        read a few vertices (GraspMotion-Opt reads ~1,100 of 10,475): the backward never forms the dense [B,V,3] gradient."""
         if not pose2rot:
             raise NotImplementedError('pose2rot=False (rotation-matrix input) is not on the GraspPose-Opt path')
 
@@ -277,8 +295,13 @@ class SMPLX(nn.Module):
             expression = expression.expand(B, -1)
         shape = torch.cat([betas, expression], dim=-1)
 
-        vertices, joints = _lbs.lbs(self, shape, full_pose, transl)
-        return SMPLXOutput(vertices=vertices if return_verts else None, joints=joints, betas=betas,
+        vertices_sel = None
+        if vertex_grad_ids is not None:
+            sel, hs = self._grad_subset(vertex_grad_ids, full_pose.device)
+            vertices, joints, vertices_sel = _lbs.lbs_selected(self, sel, hs, shape, full_pose, transl)
+        else:
+            vertices, joints = _lbs.lbs(self, shape, full_pose, transl)
+        return SMPLXOutput(vertices=vertices if return_verts else None, joints=joints, betas=betas, vertices_sel=vertices_sel,
                            expression=expression, global_orient=global_orient, body_pose=body_pose,
                            left_hand_pose=left_hand_pose, right_hand_pose=right_hand_pose, jaw_pose=jaw_pose,
                            transl=transl, full_pose=full_pose if return_full_pose else None)

@@ -95,6 +95,78 @@ class _LBS(torch.autograd.Function):
         return None, g_shape, g_pose, (g_transl if ctx.has_transl else None)
 
 
+class _LBSSelected(torch.autograd.Function):
+    """(shape, full_pose, transl) -> vertices [B,V,3] (no gradient), joints (no gradient), vertices_sel [B,U,3] = the rows
+    ``sel`` of ``vertices`` (differentiable).  For callers whose loss reads a few vertices only: the backward takes the
+    compact gradient [B,U,3] and runs on the subset model (``SMPLX.subset_handle``) -- no dense [B,V,3] gradient, no
+    zero-fill / scatter of it, and the products with its structural zeros are never formed.  Only the selected rows of
+    ``v_posed`` are kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, model, sel, hs, shape, full_pose, transl):
+        _lib.require_device(shape, full_pose, transl)         # sel: long index tensor, used by torch gathers only
+        lib = _lib.load()
+        B = full_pose.shape[0]
+        dev = full_pose.device
+        shape = shape.contiguous()
+        full_pose = full_pose.contiguous()
+        transl = None if transl is None else transl.contiguous()
+        h = model.handle(dev)
+        V, npad, njo = model.num_verts, model.npad(dev), model.num_joints_out
+        f32 = dict(device=dev, dtype=torch.float32)
+        vertices = torch.empty(B, V, 3, **f32)
+        joints = torch.empty(B, njo, 3, **f32)
+        feat = torch.empty(B, _lib.FEAT_K, **f32)
+        rot = torch.empty(B, 55, 9, **f32)
+        jrest = torch.empty(B, 55, 3, **f32)
+        chain = torch.empty(B, 55, 12, **f32)
+        A = torch.empty(B, 55, 12, **f32)
+        v_posed = torch.empty(B, npad, **f32)
+        _lib.check(lib.saga_smplx_fwd(h, _lib.ptr(shape), _lib.ptr(full_pose), _lib.ptr(transl), _lib.ptr(vertices),
+                                      _lib.ptr(joints), _lib.ptr(feat), _lib.ptr(rot), _lib.ptr(jrest), _lib.ptr(chain),
+                                      _lib.ptr(A), _lib.ptr(v_posed), B, _lib.stream()), 'saga_smplx_fwd')
+        U = sel.shape[0]
+        npad_s = lib.saga_model_npad(hs)
+        v_posed_s = torch.zeros(B, npad_s, **f32)                      # the subset model's layout: [B, Npad_s], pad = 0
+        v_posed_s[:, :3 * U] = v_posed[:, :3 * V].view(B, V, 3).index_select(1, sel).view(B, 3 * U)
+        vertices_sel = vertices.index_select(1, sel)
+        ctx.model, ctx.subset = model, hs
+        ctx.has_transl = transl is not None
+        ctx.save_for_backward(full_pose, rot, jrest, chain, A, v_posed_s)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(vertices, joints)
+        return vertices, joints, vertices_sel
+
+    @staticmethod
+    def backward(ctx, _gv, _gj, g_sel):
+        full_pose, rot, jrest, chain, A, v_posed_s = ctx.saved_tensors
+        model = ctx.model
+        if g_sel is None:
+            return None, None, None, None, None, None
+        lib = _lib.load()
+        B = full_pose.shape[0]
+        dev = full_pose.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        g_sel = g_sel.contiguous()
+        g_shape = torch.empty(B, model.num_shape, **f32)
+        g_pose = torch.empty(B, 165, **f32)
+        g_transl = torch.empty(B, 3, **f32)
+        ws_gvp = torch.empty(B, v_posed_s.shape[1], **f32)
+        ws_slab = torch.empty(_lib.BWD_SPLITK, B, _lib.FEAT_K, **f32)
+        ws_dA = torch.empty(B, _lib.DA_STRIDE, **f32)
+        _lib.check(lib.saga_smplx_bwd(ctx.subset, _lib.ptr(g_sel), None, _lib.ptr(full_pose), _lib.ptr(rot), _lib.ptr(jrest),
+                                      _lib.ptr(chain), _lib.ptr(A), _lib.ptr(v_posed_s), _lib.ptr(g_shape), _lib.ptr(g_pose),
+                                      _lib.ptr(g_transl), _lib.ptr(ws_gvp), _lib.ptr(ws_slab), _lib.ptr(ws_dA), None, B,
+                                      _lib.stream()), 'saga_smplx_bwd')
+        return None, None, None, g_shape, g_pose, (g_transl if ctx.has_transl else None)
+
+
+def lbs_selected(model, sel, hs, shape, full_pose, transl=None):
+    """``sel``: ascending unique vertex ids (long tensor on the device), ``hs``: ``model.subset_handle`` over them
+    -> (vertices, joints, vertices_sel)."""
+    return _LBSSelected.apply(model, sel, hs, shape, full_pose, transl)
+
+
 def lbs(model, shape, full_pose, transl=None):
     """Fused SMPL-X skinning on the HIP path; ``model`` is a :class:`saga_amd.smplx.SMPLX`."""
     return _LBS.apply(model, shape, full_pose, transl)
