@@ -23,6 +23,9 @@ int saga_grasp_loss_bwd_tagged(const saga_model_t* m, const saga_grasp_tables_t*
                                const float* markers_rec, const float* hand_rec, const float* h2o_signed,
                                const float* o2h_signed, const int32_t* idx_m2o, const int32_t* idx_h2o,
                                const int32_t* idx_o2h, float* g_verts, int B, int O, int32_t* zero_tag, int32_t tag, int compact, void* stream);
+int saga_smplx_fwd_sel(const saga_model_t* m, const saga_model_t* sub, const float* shape, const float* full_pose, const float* transl,
+                       float* vertices, float* joints, float* feat, float* rot, float* jrest, float* chain, float* A, float* v_posed,
+                       float* sel_rows, int B, void* stream);
 int saga_launch_gemm_nt(int epi, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, const float* bias,
                         const float* aux, int M, int N, int K, hipStream_t st);
 
@@ -350,24 +353,6 @@ __global__ __launch_bounds__(PK_THREADS) void best_update_kernel(const float* __
     if (tid == 0) best_loss[b] = l;
 }
 
-// v_posed rows of the vertices a subset model keeps, laid out as that model expects them ([B, Npad_s], pad columns 0):
-// four columns per thread, one block row per candidate
-__global__ __launch_bounds__(256) void gather_v_posed_kernel(const float* __restrict__ v_posed, int npad, const int32_t* __restrict__ sel,
-                                                             int n3, int npad_s, float* __restrict__ out) {
-    const int b = blockIdx.y;
-    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (c0 >= npad_s) return;
-    const float* src = v_posed + (size_t)b * npad;
-    float4 v;
-    float* pv = &v.x;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = c0 + k;
-        pv[k] = c < n3 ? src[sel[c / 3] * 3 + c % 3] : 0.f;
-    }
-    *reinterpret_cast<float4*>(out + (size_t)b * npad_s + c0) = v;
-}
-
 // ---- host orchestration ------------------------------------------------------------------------------------------
 struct Prof {
     void* p;
@@ -442,8 +427,10 @@ static int fit_step_impl(const saga_model_t* m, const saga_model_t* mb, const sa
                                                     nullptr, m->S, d->n_pca);
         SAGA_LAUNCH_CHECK();
     }
-    if ((rc = saga_smplx_fwd(m, w.shape, w.full_pose, w.transl, w.verts, w.joints, w.feat, w.rot, w.jrest, w.chain, w.A, w.v_posed,
-                             B, stream)))
+    // sparse backward: the skinning forward also writes the v_posed rows of the loss vertices, compact, for the subset backward
+    float* vps = mb ? w.gvp + (size_t)B * mb->Npad : nullptr;
+    if ((rc = saga_smplx_fwd_sel(m, mb, w.shape, w.full_pose, w.transl, w.verts, w.joints, w.feat, w.rot, w.jrest, w.chain, w.A,
+                                 w.v_posed, vps, B, stream)))
         return rc;
     if ((rc = saga_grasp_loss_fwd(m, tb, w.verts, prob->obj, prob->obj_normals, prob->markers_target, prob->c_markers,
                                   prob->c_object, w.terms, markers_rec, w.hand_rec, w.hand_nrm, w.h2o_marker, w.h2o_signed,
@@ -458,22 +445,15 @@ static int fit_step_impl(const saga_model_t* m, const saga_model_t* mb, const sa
     if (mb) {
         // Structurally sparse backward: the loss reads only the tables' vertices, so g_vertices is zero everywhere else and
         // every product the dense backward forms with those rows is an exact zero.  The loss backward writes the compact
-        // gradient [B,U,3], the forward's v_posed rows of those vertices are gathered, and the SMPL-X backward runs on the
+        // gradient [B,U,3], the skinning forward has written the v_posed rows of those vertices, and the SMPL-X backward runs on the
         // subset model (same joint regression, same chain; blend operand and weight tables of the U vertices only).  The
         // three compact buffers live in the dense g_v_posed workspace (contents undefined between calls anyway).
         float* gvp_s = w.gvp;
-        float* vps = gvp_s + (size_t)B * mb->Npad;
         float* g_compact = vps + (size_t)B * mb->Npad;
         if ((rc = saga_grasp_loss_bwd_tagged(m, tb, w.g_terms, w.verts, prob->obj, prob->markers_target, prob->c_markers,
                                              prob->c_object, markers_rec, w.hand_rec, w.h2o_signed, w.o2h_signed, w.idx_m2o,
                                              w.idx_h2o, w.idx_o2h, g_compact, B, O, nullptr, 0, 1, stream)))
             return rc;
-        {
-            Prof p(SAGA_PROF_SKIN_BWD, stream);
-            dim3 grid((mb->Npad / 4 + 255) / 256, B);
-            gather_v_posed_kernel<<<grid, 256, 0, st>>>(w.v_posed, m->Npad, mb->sel_ids, mb->V * 3, mb->Npad, vps);
-            SAGA_LAUNCH_CHECK();
-        }
         if ((rc = saga_smplx_bwd(mb, g_compact, nullptr, w.full_pose, w.rot, w.jrest, w.chain, w.A, vps, w.g_shape, w.g_pose,
                                  w.g_transl, gvp_s, w.slab, w.dA, nullptr, B, stream)))
             return rc;

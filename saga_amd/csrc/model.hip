@@ -31,7 +31,7 @@ extern "C" void saga_model_destroy(saga_model_t* m) {
     if (!m) return;
     void* ptrs[] = {m->Bt, m->Bk, m->v_template, m->J_template, m->J_dirs, m->parents, m->depth, m->child_ptr,
                     m->child_idx, m->w_idx, m->w_val, m->Wd, m->ds_ent, m->ds_meta, m->ds_item_ptr, m->faces, m->vf_ptr, m->vf_idx, m->vf_tri, m->lmk_verts,
-                    m->lmk_bary, m->extra_verts, m->sel_ids};
+                    m->lmk_bary, m->extra_verts, m->sel_ids, m->full_slot};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -95,8 +95,9 @@ static int model_create_impl(saga_model_t** out, const saga_model_desc_t* d, con
     const int N = m->N, Npad = m->Npad;
     int rc = 0;
     if (sel) {
-        std::vector<int32_t> ids(sel, sel + n_sel);
-        if ((rc = upload(&m->sel_ids, ids))) goto fail;
+        std::vector<int32_t> ids(sel, sel + n_sel), slot(VF, -1);
+        for (int i = 0; i < n_sel; ++i) slot[sel[i]] = i;
+        if ((rc = upload(&m->sel_ids, ids)) || (rc = upload(&m->full_slot, slot))) goto fail;
     }
 
     {   // blend operands, both orientations

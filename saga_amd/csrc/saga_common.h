@@ -92,6 +92,7 @@ struct saga_model {
     // (ascending); a full model has VF = V and sel_ids = NULL
     int VF;
     int32_t* sel_ids;
+    int32_t* full_slot;   // [VF]: row of full-mesh vertex v in this subset, or -1 (NULL for a full model)
 };
 
 static inline int saga_roundup(int x, int m) { return (x + m - 1) / m * m; }

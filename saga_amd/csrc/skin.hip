@@ -23,12 +23,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef SKIN_VPT
 #define SKIN_VPT 4
 #endif
-template <bool KW4>
+// SEL (saga_fit_step_sparse): the v_posed rows of the vertices a subset model keeps are also written, compact, in that model's
+// layout (sel_rows [B, npad_s], pad columns 0; sel_slot[v] = row of full-mesh vertex v in the subset or -1) while they are in
+// registers -- a separate gather would touch nearly every 128-B line of v_posed again (0.07 ms at B = 4096).
+template <bool KW4, bool SEL = false>
 __global__ __launch_bounds__(SKIN_THREADS) void skin_fwd_kernel(const float* __restrict__ A, const float* __restrict__ v_posed,
                                                                 const int32_t* __restrict__ w_idx,
                                                                 const float* __restrict__ w_val,
                                                                 const float* __restrict__ transl, float* __restrict__ verts,
-                                                                int V, int Npad, int KW) {
+                                                                int V, int Npad, int KW,
+                                                                const int32_t* __restrict__ sel_slot = nullptr,
+                                                                float* __restrict__ sel_rows = nullptr, int n_sel3 = 0, int npad_s = 0) {
     __shared__ __attribute__((aligned(16))) float sA[NJ * 12];
     const int b = blockIdx.y;
     const int vbase = blockIdx.x * (SKIN_THREADS * SKIN_VPT);
@@ -38,9 +43,11 @@ __global__ __launch_bounds__(SKIN_THREADS) void skin_fwd_kernel(const float* __r
     float px[SKIN_VPT], py[SKIN_VPT], pz[SKIN_VPT];
     int4 ji[SKIN_VPT];
     float4 wv[SKIN_VPT];
+    int slot[SKIN_VPT];
 #pragma unroll
     for (int i = 0; i < SKIN_VPT; ++i) {
         const int v = min(vbase + i * SKIN_THREADS + tid, V - 1);
+        if (SEL) slot[i] = sel_slot[v];
         typedef float f32x3_t __attribute__((ext_vector_type(3)));
         const f32x3_t pv = __builtin_nontemporal_load(reinterpret_cast<const f32x3_t*>(src + v * 3));   // one 12-B load, read once
         const float3 p3 = make_float3(pv.x, pv.y, pv.z);
@@ -53,10 +60,16 @@ __global__ __launch_bounds__(SKIN_THREADS) void skin_fwd_kernel(const float* __r
     const float tx = transl ? transl[b * 3] : 0.f, ty = transl ? transl[b * 3 + 1] : 0.f, tz = transl ? transl[b * 3 + 2] : 0.f;
     __syncthreads();
     float* dst = verts + (size_t)b * V * 3;
+    if (SEL && blockIdx.x == 0)
+        for (int c = n_sel3 + tid; c < npad_s; c += SKIN_THREADS) sel_rows[(size_t)b * npad_s + c] = 0.f;
 #pragma unroll
     for (int i = 0; i < SKIN_VPT; ++i) {
         const int v = vbase + i * SKIN_THREADS + tid;
         if (v >= V) continue;
+        if (SEL && slot[i] >= 0) {
+            float* r = sel_rows + (size_t)b * npad_s + slot[i] * 3;
+            r[0] = px[i]; r[1] = py[i]; r[2] = pz[i];
+        }
         float T[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) T[k] = 0.f;
@@ -648,6 +661,22 @@ __global__ __launch_bounds__(DS_THREADS, 4) void skin_bwd_sparse_kernel(
         }
         out[o] = s;
     }
+}
+
+// sub (may be NULL): subset model over this mesh; its rows of v_posed are also written to sel_rows [B, sub->Npad]
+int saga_launch_skin_fwd_sel(const saga_model* m, const saga_model* sub, const float* A, const float* v_posed, const float* transl,
+                             float* verts, float* sel_rows, int B, hipStream_t st) {
+    const int per_block = SKIN_THREADS * SKIN_VPT;
+    dim3 grid((m->V + per_block - 1) / per_block, B);
+    SAGA_CHECK_ARG(sub && sub->full_slot && sub->VF == m->V && sel_rows, "skin_fwd_sel: not a subset model of this mesh");
+    if (m->KW == 4)
+        skin_fwd_kernel<true, true><<<grid, SKIN_THREADS, 0, st>>>(A, v_posed, m->w_idx, m->w_val, transl, verts, m->V, m->Npad, m->KW,
+                                                                   sub->full_slot, sel_rows, sub->V * 3, sub->Npad);
+    else
+        skin_fwd_kernel<false, true><<<grid, SKIN_THREADS, 0, st>>>(A, v_posed, m->w_idx, m->w_val, transl, verts, m->V, m->Npad, m->KW,
+                                                                    sub->full_slot, sel_rows, sub->V * 3, sub->Npad);
+    SAGA_LAUNCH_CHECK();
+    return 0;
 }
 
 int saga_launch_skin_fwd(const saga_model* m, const float* A, const float* v_posed, const float* transl, float* verts, int B,

@@ -10,6 +10,8 @@ int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed
 int saga_launch_blend_bwd(const saga_model* m, const float* g_vposed, float* slabs, int B, hipStream_t st);
 int saga_launch_skin_fwd(const saga_model* m, const float* A, const float* v_posed, const float* transl, float* verts, int B,
                          hipStream_t st);
+int saga_launch_skin_fwd_sel(const saga_model* m, const saga_model* sub, const float* A, const float* v_posed, const float* transl,
+                             float* verts, float* sel_rows, int B, hipStream_t st);
 int saga_launch_joints_fwd(const saga_model* m, const float* chain, const float* verts, const float* transl, float* joints, int B,
                            hipStream_t st);
 int saga_launch_joints_bwd(const saga_model* m, const float* g_joints, float* g_pj, float* g_jsum, float* gv, int B,
@@ -68,9 +70,21 @@ extern "C" int saga_profile_read(double* total_ms_host, int32_t* count_host) {
 
 #define PROF(id) ProfScope prof_scope_##id(id, st)
 
+// sub / sel_rows (both NULL for the plain forward): see saga_launch_skin_fwd_sel; used by saga_fit_step_sparse
+int saga_smplx_fwd_sel(const saga_model_t* m, const saga_model_t* sub, const float* shape, const float* full_pose, const float* transl,
+                       float* vertices, float* joints, float* feat, float* rot, float* jrest, float* chain, float* A, float* v_posed,
+                       float* sel_rows, int B, void* stream);
+
 extern "C" int saga_smplx_fwd(const saga_model_t* m, const float* shape, const float* full_pose, const float* transl,
                               float* vertices, float* joints, float* feat, float* rot, float* jrest, float* chain, float* A,
                               float* v_posed, int B, void* stream) {
+    return saga_smplx_fwd_sel(m, nullptr, shape, full_pose, transl, vertices, joints, feat, rot, jrest, chain, A, v_posed, nullptr, B,
+                              stream);
+}
+
+int saga_smplx_fwd_sel(const saga_model_t* m, const saga_model_t* sub, const float* shape, const float* full_pose, const float* transl,
+                       float* vertices, float* joints, float* feat, float* rot, float* jrest, float* chain, float* A, float* v_posed,
+                       float* sel_rows, int B, void* stream) {
     SAGA_CHECK_ARG(m, "saga_smplx_fwd: null model");
     SAGA_CHECK_ARG(B >= 0 && B <= 65535, "saga_smplx_fwd: batch %d outside [0, 65535]", B);
     if (B == 0) return 0;
@@ -80,7 +94,12 @@ extern "C" int saga_smplx_fwd(const saga_model_t* m, const float* shape, const f
     int rc;
     { PROF(SAGA_PROF_POSE_FWD); if ((rc = saga_launch_pose_fwd(m, shape, full_pose, feat, rot, jrest, chain, A, B, st))) return rc; }
     { PROF(SAGA_PROF_BLEND_FWD); if ((rc = saga_launch_blend_fwd(m, feat, v_posed, B, st))) return rc; }
-    { PROF(SAGA_PROF_SKIN_FWD); if ((rc = saga_launch_skin_fwd(m, A, v_posed, transl, vertices, B, st))) return rc; }
+    {
+        PROF(SAGA_PROF_SKIN_FWD);
+        if ((rc = sub ? saga_launch_skin_fwd_sel(m, sub, A, v_posed, transl, vertices, sel_rows, B, st)
+                      : saga_launch_skin_fwd(m, A, v_posed, transl, vertices, B, st)))
+            return rc;
+    }
     if (joints) { PROF(SAGA_PROF_JOINTS); if ((rc = saga_launch_joints_fwd(m, chain, vertices, transl, joints, B, st))) return rc; }
     return 0;
 }
