@@ -200,21 +200,6 @@ def main():
     _lib.profile_enable(False)
     prof = _lib.profile_read()
 
-    # separately reported variant, untimed region of its own (never the headline): the same iteration through
-    # saga_fit_step_sparse -- full-mesh forward, backward over the vertices the loss reads
-    variant = None
-    if not (args.autograd or args.sparse_backward or args.loss_vertices_only):
-        op.sparse_backward = True
-        for _ in range(3):
-            step(op, d, None)
-        barrier()
-        tv = time.perf_counter()
-        for _ in range(args.steps):
-            step(op, d, None)
-        barrier()
-        variant = (time.perf_counter() - tv) / args.steps * 1e3
-        op.sparse_backward = False
-
     t_max = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -270,11 +255,10 @@ def main():
         if args.sparse_backward:        # the dense algorithmic figures do not describe this variant's backward kernels
             for k in ('blend_gemm_bwd', 'skin_bwd', 'grasp_loss_bwd'):
                 out['config']['stages'].pop(k, None)
-        if variant is not None:
-            out['config']['variant_sparse_backward'] = {
-                'ms_per_step': round(variant, 4),
-                'note': 'NOT the headline: saga_fit_step_sparse, same full-mesh forward, backward over the %d vertices the loss '
-                        'reads (the dense vertex gradient is zero elsewhere); measured after the timed region' % op.tables.n_unique}
+        if not (args.sparse_backward or args.loss_vertices_only or args.autograd or args.local_weights):
+            out['config']['variants_reported_separately'] = (
+                'bench.py --sparse-backward (saga_fit_step_sparse: same full-mesh forward, backward over the loss vertices only; '
+                'profiles/round1_k_sparse_backward_bench.json: 2.99 ms per iteration) and --loss-vertices-only; never the headline')
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only (host cores are shared by the ranks)
             cand_per_s, threads, dt = cpu_baseline(tmp.name, vp, n_obj, args.cpu_batch, args.cpu_iters)
             out['cpu_baseline'] = {

@@ -8,6 +8,8 @@
 // v_mfma_f32_32x32x2_f32 is an exact f32 FMA chain (no xf32 on gfx950): lanes 0-31 supply k = 8g+t, lanes 32-63
 // k = 8g+4+t for MFMA t of k-group g -- any k permutation is valid as long as A and B agree.
 // Replaces smplx.lbs.blend_shapes + the posedirs matmul.
+#include <algorithm>
+
 #include "saga_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -234,11 +236,17 @@ int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed
     return 0;
 }
 
+// Split-K slabs of the backward contraction: 16 for the whole mesh; a vertex subset (K = 3 x a few hundred to a few thousand) gets
+// one slab per 768 columns so that a block still runs >= 48 k-tiles.  A function of the model only: a candidate's sums must
+// not depend on the batch size.
+int saga_blend_bwd_splitk(const saga_model* m) { return std::min(SAGA_BWD_SPLITK, std::max(1, m->Npad / 768)); }
+
 // slabs[z][B][512] = g_v_posed[:, kz] . Bk[:, kz]^T
 int saga_launch_blend_bwd(const saga_model* m, const float* g_vposed, float* slabs, int B, hipStream_t st) {
     const int tiles_m = (B + BM - 1) / BM, tiles_n = FEAT_K / BN;
-    const int kchunk = saga_roundup((m->Npad + SAGA_BWD_SPLITK - 1) / SAGA_BWD_SPLITK, 32);
-    dim3 grid(tiles_m * tiles_n, 1, SAGA_BWD_SPLITK);
+    const int splitk = saga_blend_bwd_splitk(m);
+    const int kchunk = saga_roundup((m->Npad + splitk - 1) / splitk, 32);
+    dim3 grid(tiles_m * tiles_n, 1, splitk);
     gemm_nt_f32_kernel<1, GEMM_BKT, GEMM_NST_BWD><<<grid, 256, 0, st>>>(g_vposed, m->Npad, m->Bk, m->Npad, slabs, FEAT_K, nullptr, nullptr, B, FEAT_K,
                                                 m->Npad, kchunk, tiles_m);
     SAGA_LAUNCH_CHECK();

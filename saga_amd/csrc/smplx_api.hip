@@ -8,6 +8,7 @@ int saga_launch_pose_bwd(const saga_model* m, const float* dA, const float* g_pj
                          float* g_shape, float* g_full_pose, float* g_transl, int B, int has_verts, hipStream_t st);
 int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed, int B, hipStream_t st);
 int saga_launch_blend_bwd(const saga_model* m, const float* g_vposed, float* slabs, int B, hipStream_t st);
+int saga_blend_bwd_splitk(const saga_model* m);
 int saga_launch_skin_fwd(const saga_model* m, const float* A, const float* v_posed, const float* transl, float* verts, int B,
                          hipStream_t st);
 int saga_launch_skin_fwd_sel(const saga_model* m, const saga_model* sub, const float* A, const float* v_posed, const float* transl,
@@ -144,6 +145,6 @@ extern "C" int saga_smplx_bwd(const saga_model_t* m, const float* g_vertices, co
         { PROF(SAGA_PROF_BLEND_BWD); if ((rc = saga_launch_blend_bwd(m, ws_gvp, ws_slab, B, st))) return rc; }
     }
     PROF(SAGA_PROF_POSE_BWD);
-    return saga_launch_pose_bwd(m, ws_dA, g_pj, g_jsum, ws_slab, SAGA_BWD_SPLITK, rot, jrest, chain, full_pose, g_shape, g_full_pose,
+    return saga_launch_pose_bwd(m, ws_dA, g_pj, g_jsum, ws_slab, saga_blend_bwd_splitk(m), rot, jrest, chain, full_pose, g_shape, g_full_pose,
                                 g_transl, B, has_verts, st);
 }
