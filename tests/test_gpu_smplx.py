@@ -156,3 +156,40 @@ def test_cpu_tensor_is_rejected(small_model_dir):
                       vertex_ids=small_vertex_ids(203))
     with pytest.raises(RuntimeError):
         bm()        # parameters still on the CPU: no fallback
+
+
+@pytest.mark.parametrize('small', [True, False])
+def test_vertex_grad_ids_matches_dense_backward(small_model_dir, body_model_dir, small):
+    """forward(vertex_grad_ids=ids): `vertices_sel` equals `vertices[:, ids]` bit for bit, `vertices` / `joints` carry no
+    gradient, and a loss on `vertices_sel` gives the input gradients of the same loss on the dense path (backward on the
+    subset model: the skipped terms are exact zeros) -- also against the float64 oracle."""
+    root = small_model_dir if small else body_model_dir
+    B = 5
+    hip = make_hip_model(root, B, small=small)
+    ref = load_oracle_model(root, B, small=small)
+    V = hip.num_verts
+    g = torch.Generator().manual_seed(11)
+    ids = torch.sort(torch.randperm(V, generator=g)[:max(7, V // 10)]).values.cuda()
+    inp = random_body_inputs(B, seed=21)
+    w = torch.randn(B, ids.shape[0], 3, generator=g, dtype=torch.float64)
+    a = to_cuda(inp, requires_grad=True)
+    b = to_cuda(inp, requires_grad=True)
+    out_a = hip(return_verts=True, vertex_grad_ids=ids, **a)
+    out_b = hip(return_verts=True, **b)
+    assert torch.equal(out_a.vertices, out_b.vertices) and torch.equal(out_a.joints, out_b.joints)
+    assert torch.equal(out_a.vertices_sel, out_b.vertices[:, ids])
+    assert not out_a.vertices.requires_grad and not out_a.joints.requires_grad and out_a.vertices_sel.requires_grad
+    (out_a.vertices_sel * w.float().cuda()).sum().backward()
+    (out_b.vertices.index_select(1, ids) * w.float().cuda()).sum().backward()
+    r = {k: v.clone().requires_grad_(True) for k, v in inp.items()}
+    (ref(**r)['vertices'][:, ids.cpu()] * w).sum().backward()
+    for k in ('betas', 'global_orient', 'body_pose', 'left_hand_pose', 'right_hand_pose', 'transl', 'expression', 'jaw_pose'):
+        ga, gb = a[k].grad.cpu().numpy(), b[k].grad.cpu().numpy()
+        assert rel_err(ga, gb) < 2e-5, (k, rel_err(ga, gb))
+        assert rel_err(ga, r[k].grad.numpy()) < GRAD_TOL, (k, rel_err(ga, r[k].grad.numpy()))
+    # a second call with the same id tensor reuses the cached subset model; unsorted ids are rejected
+    n_handles = len(hip._handles)
+    hip(return_verts=True, vertex_grad_ids=ids, **to_cuda(inp))
+    assert len(hip._handles) == n_handles
+    with pytest.raises(ValueError):
+        hip(return_verts=True, vertex_grad_ids=torch.flip(ids, [0]), **to_cuda(inp))
