@@ -248,8 +248,8 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_f32_kernel (blend contraction, fwd+bwd launches)',
                          'achieved': None if achieved is None else round(achieved, 2), 'peak': PEAK_F32_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': None if achieved is None else round(achieved / PEAK_F32_TFLOPS, 4),
-                         'traffic': None if args.loss_vertices_only else pmc_traffic(),
-                         'traffic_note': 'HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/); '
+                         'traffic': None if (args.loss_vertices_only or args.sparse_backward) else pmc_traffic(),
+                         'traffic_note': 'HBM-side bytes per launch, mean of the forward and backward launches (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/); '
                                          'algorithmic bytes per launch = %d' % int(B * 3 * V_eval * 4 + B * 512 * 4 + 3 * V_eval * 512 * 4)},
         }
         if args.sparse_backward:        # the dense algorithmic figures do not describe this variant's backward kernels
@@ -258,7 +258,7 @@ def main():
         if not (args.sparse_backward or args.loss_vertices_only or args.autograd or args.local_weights):
             out['config']['variants_reported_separately'] = (
                 'bench.py --sparse-backward (saga_fit_step_sparse: same full-mesh forward, backward over the loss vertices only; '
-                'profiles/round1_k_sparse_backward_bench.json: 2.99 ms per iteration) and --loss-vertices-only; never the headline')
+                'profiles/round1_k_sparse_backward_bench.json: 2.9-3.0 ms per iteration) and --loss-vertices-only; never the headline')
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only (host cores are shared by the ranks)
             cand_per_s, threads, dt = cpu_baseline(tmp.name, vp, n_obj, args.cpu_batch, args.cpu_iters)
             out['cpu_baseline'] = {

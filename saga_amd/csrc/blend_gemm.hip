@@ -8,6 +8,8 @@
 // v_mfma_f32_32x32x2_f32 is an exact f32 FMA chain (no xf32 on gfx950): lanes 0-31 supply k = 8g+t, lanes 32-63
 // k = 8g+4+t for MFMA t of k-group g -- any k permutation is valid as long as A and B agree.
 // Replaces smplx.lbs.blend_shapes + the posedirs matmul.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "saga_common.h"
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
                                                           const float* __restrict__ Bt, int ldb, float* __restrict__ C,
                                                           int ldc, const float* __restrict__ bias,
                                                           const float* __restrict__ aux, int M, int N, int K,
-                                                          int kchunk, int tiles_m) {
+                                                          int kchunk, int tiles_m, int xcd_map = 0) {
     constexpr int TBM = 64 * WT, TBN = 64 * WT;      // block tile
     constexpr int TILE_FLOATS = TBM * BKT;           // one operand tile
     constexpr int PPW = TILE_FLOATS * 4 / 1024 / 4;  // 1-KiB LDS-DMA pieces per wave per operand tile: 4 (BKT 32) / 2 (16)
@@ -64,10 +66,29 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     __shared__ __attribute__((aligned(1024))) float smem[NST * 2 * TILE_FLOATS];   // [stage][A|B][128][BKT]
 
     // consecutive blocks walk M first so the (large, batch-shared) Bt tile stays hot in L2 while A is re-read
-    const int tile_m = blockIdx.x % tiles_m;
-    const int tile_n = blockIdx.x / tiles_m;
+    int tile_m = blockIdx.x % tiles_m;
+    int tile_n = blockIdx.x / tiles_m;
+    int slab = blockIdx.z;
+    if (xcd_map == 2) {
+        // split-K launch (gridDim.z a multiple of 8): XCD x owns the slabs z = x (mod 8) entirely, so every A and B tile of the
+        // launch is fetched by exactly one L2 (linear workgroup id = z * gridDim.x + x, dealt to the XCDs round-robin)
+        const int per = gridDim.x;
+        const int L = blockIdx.z * per + blockIdx.x;
+        const int x = L & 7, i = L >> 3;
+        slab = x + 8 * (i / per);
+        const int t = i % per, tiles_n = per / tiles_m;
+        tile_n = t % tiles_n;          // the N tiles of one M tile run together: its (large, streamed) A rows are fetched once
+        tile_m = t / tiles_n;
+    } else if (xcd_map) {
+        // workgroups go to the 8 XCDs round-robin: XCD x owns a quarter of the M tiles (its A rows stay in its L2) and half of the
+        // N tiles, so a Bt tile is fetched by four L2s instead of eight (host checks tiles_m % 4 == 0 and tiles_n % 2 == 0)
+        const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int mq = tiles_m >> 2, nh = (gridDim.x / tiles_m) >> 1;
+        tile_m = (x & 3) * mq + i % mq;
+        tile_n = (x >> 2) * nh + i / mq;
+    }
     const int m0 = tile_m * TBM, n0 = tile_n * TBN;
-    const int k_begin = blockIdx.z * kchunk;
+    const int k_begin = slab * kchunk;
     const int k_end = min(K, k_begin + kchunk);
     const int T = (k_end - k_begin) / BKT;
 
@@ -161,7 +182,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* Cz = C;
-    if (EPI == 1) Cz += (size_t)blockIdx.z * M * ldc;
+    if (EPI == 1) Cz += (size_t)slab * M * ldc;
     const bool full = (m0 + TBM <= M);       // N is always a multiple of BN here (Npad / 512)
     if (TRS) {
         // transposed tiles: row = lane&31, col = (r&3) + 8*(r>>2) + 4*(lane>>5): one 16-B store per register quad
@@ -230,8 +251,10 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
 int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed, int B, hipStream_t st) {
     const int tiles_m = (B + BM - 1) / BM, tiles_n = m->Npad / BN;
     dim3 grid(tiles_m * tiles_n, 1, 1);
+    static const int want_xcd = getenv("SAGA_GEMM_XCD") ? atoi(getenv("SAGA_GEMM_XCD")) : 1;     // SAGA_GEMM_XCD=0: plain tile order (A/B)
+    const int xcd_map = want_xcd && tiles_m % 4 == 0 && tiles_n % 2 == 0;
     gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD><<<grid, 256, 0, st>>>(feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template, nullptr, B, m->Npad,
-                                                FEAT_K, FEAT_K, tiles_m);
+                                                FEAT_K, FEAT_K, tiles_m, xcd_map);
     SAGA_LAUNCH_CHECK();
     return 0;
 }
@@ -247,8 +270,10 @@ int saga_launch_blend_bwd(const saga_model* m, const float* g_vposed, float* sla
     const int splitk = saga_blend_bwd_splitk(m);
     const int kchunk = saga_roundup((m->Npad + splitk - 1) / splitk, 32);
     dim3 grid(tiles_m * tiles_n, 1, splitk);
+    static const int want_xcd = getenv("SAGA_GEMM_XCD") ? atoi(getenv("SAGA_GEMM_XCD")) : 1;     // SAGA_GEMM_XCD=0: plain tile order (A/B)
+    const int xcd_map = (want_xcd && splitk % 8 == 0) ? 2 : 0;
     gemm_nt_f32_kernel<1, GEMM_BKT, GEMM_NST_BWD><<<grid, 256, 0, st>>>(g_vposed, m->Npad, m->Bk, m->Npad, slabs, FEAT_K, nullptr, nullptr, B, FEAT_K,
-                                                m->Npad, kchunk, tiles_m);
+                                                m->Npad, kchunk, tiles_m, xcd_map);
     SAGA_LAUNCH_CHECK();
     return 0;
 }
