@@ -370,7 +370,10 @@ class FittingOP:
                 ctypes.byref(cfg), P(self.vars), P(o['m']), P(o['v']), P(self._workspace(problem['struct'].n_obj)), P(problem['loss']),
                 P(loss_terms), P(problem['markers_rec']), self.batch_size, _lib.stream())
         if self.sparse_backward:
-            m_loss = self.bm.subset_handle(self.device, self.tables.unique_ids_host)
+            cached = getattr(self, '_m_loss', None)
+            if cached is None or cached[0] is not self.bm:       # subset model of the current body model, looked up once
+                cached = self._m_loss = (self.bm, self.bm.subset_handle(self.device, self.tables.unique_ids_host))
+            m_loss = cached[1]
             _lib.check(_lib.load().saga_fit_step_sparse(self.bm.handle(self.device), m_loss, *rest), 'saga_fit_step_sparse')
         else:
             _lib.check(_lib.load().saga_fit_step(self.bm.handle(self.device), *rest), 'saga_fit_step')
