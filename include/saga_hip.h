@@ -267,6 +267,9 @@ typedef struct {
     int32_t update_mask;    /* SAGA_GROUP_* bits: the variables the optimiser of this stage owns (:77-79) */
     int32_t adam_step;      /* 1-based step count of that optimiser */
     float lr, beta1, beta2, eps;
+    int32_t skip_gated_terms; /* 1: in a stage whose contact / collision weights are all zero (stage < 2, or only_rec) those terms
+                                 and the four counts are not evaluated and come back as 0 (the reference evaluates and logs them
+                                 although they do not reach the loss, fittingop.py:215-242); 0: the reference's behaviour */
 } saga_fit_step_cfg_t;
 
 /* floats of workspace saga_fit_step / saga_fit_decode need for B candidates and O object points */

@@ -72,7 +72,8 @@ class FitProblem(ctypes.Structure):
 class FitStepCfg(ctypes.Structure):
     _fields_ = [('stage', ctypes.c_int32), ('only_rec', ctypes.c_int32), ('prior_contact', ctypes.c_int32),
                 ('update_mask', ctypes.c_int32), ('adam_step', ctypes.c_int32),
-                ('lr', ctypes.c_float), ('beta1', ctypes.c_float), ('beta2', ctypes.c_float), ('eps', ctypes.c_float)]
+                ('lr', ctypes.c_float), ('beta1', ctypes.c_float), ('beta2', ctypes.c_float), ('eps', ctypes.c_float),
+                ('skip_gated_terms', ctypes.c_int32)]
 
 # name -> (restype, argtypes); every symbol include/saga_hip.h declares
 PROTOTYPES = {

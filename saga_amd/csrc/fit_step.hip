@@ -26,6 +26,8 @@ int saga_grasp_loss_bwd_tagged(const saga_model_t* m, const saga_grasp_tables_t*
 int saga_smplx_fwd_sel(const saga_model_t* m, const saga_model_t* sub, const float* shape, const float* full_pose, const float* transl,
                        float* vertices, float* joints, float* feat, float* rot, float* jrest, float* chain, float* A, float* v_posed,
                        float* sel_rows, int B, void* stream);
+int saga_grasp_loss_fwd_rec(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* verts, const float* markers_target,
+                            float* terms, float* markers_rec, int32_t* idx_m2o, int B, void* stream);
 int saga_launch_gemm_nt(int epi, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, const float* bias,
                         const float* aux, int M, int N, int K, hipStream_t st);
 
@@ -432,9 +434,14 @@ static int fit_step_impl(const saga_model_t* m, const saga_model_t* mb, const sa
     if ((rc = saga_smplx_fwd_sel(m, mb, w.shape, w.full_pose, w.transl, w.verts, w.joints, w.feat, w.rot, w.jrest, w.chain, w.A,
                                  w.v_posed, vps, B, stream)))
         return rc;
-    if ((rc = saga_grasp_loss_fwd(m, tb, w.verts, prob->obj, prob->obj_normals, prob->markers_target, prob->c_markers,
-                                  prob->c_object, w.terms, markers_rec, w.hand_rec, w.hand_nrm, w.h2o_marker, w.h2o_signed,
-                                  w.o2h_signed, w.idx_m2o, w.idx_h2o, w.idx_o2h, B, O, stream)))
+    // every contact / collision term has weight 0 in stages 0 and 1 (and with only_rec): the reference still evaluates and logs
+    // them; with skip_gated_terms they are neither evaluated nor logged (written as 0) -- no NN scan, no hand normals
+    const bool gated_off = cfg->skip_gated_terms && (cfg->stage < 2 || cfg->only_rec);
+    if (gated_off) {
+        if ((rc = saga_grasp_loss_fwd_rec(m, tb, w.verts, prob->markers_target, w.terms, markers_rec, w.idx_m2o, B, stream))) return rc;
+    } else if ((rc = saga_grasp_loss_fwd(m, tb, w.verts, prob->obj, prob->obj_normals, prob->markers_target, prob->c_markers,
+                                         prob->c_object, w.terms, markers_rec, w.hand_rec, w.hand_nrm, w.h2o_marker, w.h2o_signed,
+                                         w.o2h_signed, w.idx_m2o, w.idx_h2o, w.idx_o2h, B, O, stream)))
         return rc;
     {
         Prof p(SAGA_PROF_LOSS_SUM, stream);

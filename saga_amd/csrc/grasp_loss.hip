@@ -562,6 +562,49 @@ __global__ __launch_bounds__(GL_BWD_THREADS) void grasp_loss_bwd_kernel(
     if (zero_tag && tid == 0) zero_tag[b] = tag;
 }
 
+// The terms a stage with every contact / collision weight gated off needs (fittingop.py:215-223 with stage < 2 or only_rec):
+// marker reconstruction (:168-169) and the foot term (:173); the gated terms and the four counts are written as 0.  One block per
+// candidate; lane partials in query order, wave partials in wave order (fixed summation order).
+__global__ __launch_bounds__(GL_THREADS) void grasp_loss_fwd_rec_kernel(saga_grasp_tables_t tb, const float* __restrict__ verts,
+                                                                        const float* __restrict__ mk_target, float* __restrict__ terms,
+                                                                        float* __restrict__ markers_rec, int32_t* __restrict__ idx_m2o,
+                                                                        int V) {
+#pragma clang fp contract(off)
+    __shared__ float red[GL_THREADS / 64][3];
+    const int b = blockIdx.x, tid = threadIdx.x, M = tb.n_markers;
+    const float* vb = verts + (size_t)b * V * 3;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int p = tid; p < M; p += GL_THREADS) {
+        const int v = tb.marker_ids[p];
+        const float x = vb[v * 3], y = vb[v * 3 + 1], z = vb[v * 3 + 2];
+        float* dst = markers_rec + ((size_t)b * M + p) * 3;
+        dst[0] = x; dst[1] = y; dst[2] = z;
+        idx_m2o[(size_t)b * M + p] = 0;       // the backward forms (marker - obj[idx]) before it multiplies by the zero weight
+        const float* tg = mk_target + ((size_t)b * M + p) * 3;
+        const float e = (fabsf(x - tg[0]) + fabsf(y - tg[1])) + fabsf(z - tg[2]);
+        s0 += e;
+        if (p < tb.n_body_markers) s1 += e;
+    }
+    for (int i = tid; i < tb.n_foot; i += GL_THREADS) s2 += fabsf(vb[tb.foot_ids[i] * 3 + 2]);
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_down(s0, o, 64); s1 += __shfl_down(s1, o, 64); s2 += __shfl_down(s2, o, 64);
+    }
+    if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; red[wave][2] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        float sm[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sm[i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+        float* t = terms + (size_t)b * NT;
+        t[0] = sm[0] / (float)(M * 3);
+        t[1] = sm[1] / (float)(tb.n_body_markers * 3);
+        t[2] = 0.1f * (sm[2] / (float)tb.n_foot);
+#pragma unroll
+        for (int i = 3; i < NT; ++i) t[i] = 0.f;
+    }
+}
+
 static int check_tables(const saga_grasp_tables_t* tb) {
     SAGA_CHECK_ARG(tb, "grasp loss: null tables");
     SAGA_CHECK_ARG(tb->n_hand > 0 && tb->n_hand <= GL_MAX_HAND && tb->n_markers > 0 && tb->n_markers <= GL_MAX_MARK &&
@@ -600,6 +643,21 @@ extern "C" int saga_grasp_loss_fwd(const saga_model_t* m, const saga_grasp_table
                                                                          markers_target, c_markers, c_object, terms, markers_rec,
                                                                          hand_rec, hand_normals, h2o_marker, h2o_signed, o2h_signed,
                                                                          idx_m2o, idx_h2o, idx_o2h, m->V, O);
+    saga_prof_end(prof);
+    SAGA_LAUNCH_CHECK();
+    return 0;
+}
+
+// saga_fit_step with cfg->skip_gated_terms in a stage whose contact / collision weights are all zero
+int saga_grasp_loss_fwd_rec(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* verts, const float* markers_target,
+                            float* terms, float* markers_rec, int32_t* idx_m2o, int B, void* stream) {
+    SAGA_CHECK_ARG(m && idx_m2o, "saga_grasp_loss_fwd_rec: null model");
+    int rc = check_tables(tb);
+    if (rc) return rc;
+    SAGA_CHECK_ARG(B >= 0 && verts && markers_target && terms && markers_rec, "saga_grasp_loss_fwd_rec: bad arguments");
+    if (B == 0) return 0;
+    void* prof = saga_prof_begin(SAGA_PROF_GRASP_FWD, stream);
+    grasp_loss_fwd_rec_kernel<<<B, GL_THREADS, 0, (hipStream_t)stream>>>(*tb, verts, markers_target, terms, markers_rec, idx_m2o, m->V);
     saga_prof_end(prof);
     SAGA_LAUNCH_CHECK();
     return 0;

@@ -65,14 +65,16 @@ class FittingOP:
     the drop-in operators + ``torch.optim.Adam``, the form the reference has), ``record_history``, ``sparse_backward``
     (native path only, default False: ``saga_fit_step_sparse`` -- the backward runs over the ~1,050 vertices the loss reads
     instead of multiplying the structural zeros of the dense [B,V,3] vertex gradient through the whole mesh; the forward
-    is unchanged and the gradients agree to rounding)."""
+    is unchanged and the gradients agree to rounding), ``log_gated_terms`` (native path only, default True = the reference:
+    stages 1 and 2 evaluate and log the contact / collision terms although their weights are zero there; False: those
+    stages skip the nearest-neighbour search and the hand normals, and ``save_loss`` holds 0 for the gated keys)."""
 
     def __init__(self, fittingconfig):
         cfg = dict(init_lr_h=0.008, num_iter=[300, 400, 500], batch_size=1, num_markers=143, device='cuda',
                    verbose=False, hand_ncomps=24, only_rec=False, contact_loss='contact', logger=print,
                    data_type='markers_143', body_model_path='./body_utils/body_models', vposer=None, indices=None,
                    smplx_kwargs={}, genders=('male', 'female'), fused=True, native=True,
-                   record_history=True, loss_vertices_only=False, sparse_backward=False)
+                   record_history=True, loss_vertices_only=False, sparse_backward=False, log_gated_terms=True)
         cfg.update(fittingconfig)
         for key, val in cfg.items():
             setattr(self, key, val)
@@ -364,7 +366,7 @@ class FittingOP:
         o = self._native_opt[ss]
         o['step'] += 1
         cfg = _lib.FitStepCfg(ss, int(bool(self.only_rec)), int(self.contact_loss == 'prior'), o['mask'], o['step'],
-                              o['lr'], 0.9, 0.999, 1e-8)
+                              o['lr'], 0.9, 0.999, 1e-8, int(not self.log_gated_terms))
         P = _lib.ptr
         rest = (self._native_handles(), ctypes.byref(self.tables.struct), ctypes.byref(problem['struct']),
                 ctypes.byref(cfg), P(self.vars), P(o['m']), P(o['v']), P(self._workspace(problem['struct'].n_obj)), P(problem['loss']),

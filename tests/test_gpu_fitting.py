@@ -334,3 +334,29 @@ def test_sparse_backward_rejects_wrong_subset_model(body_model_dir):
                                           _lib.stream())
     assert rc != 0
 
+
+
+def test_unlogged_gated_terms_give_the_same_fit(body_model_dir):
+    """log_gated_terms=False: stages 1 and 2 (every contact / collision weight is zero there) skip the NN search and the
+    hand normals.  Same total / rec / foot / reg curves and the same variables as the reference behaviour up to the rounding of
+    a different summation order in the three remaining means; the gated keys are logged as 0 in those stages only."""
+    B, num_iter = 4, (3, 3, 3)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    out = []
+    for log in (True, False):
+        op, vp, idx, _, d = _setup(body_model_dir, B, num_iter=num_iter)
+        op.log_gated_terms = log
+        out.append(op.fitting(cu(d['markers']), cu(d['oc']), cu(d['mc']), cu(d['verts_o']), cu(d['normals_o']), 'male'))
+    (mf_a, p_a, sl_a), (mf_b, p_b, sl_b) = out
+    gated = ['marker contact', 'object contact', 'prior contact', 'hand collision', 'object collision'] + list(loss_ref.COUNT_KEYS)
+    for k in sl_a:
+        if k in gated:
+            assert not np.any(sl_b[k][:6]), k
+            assert np.any(sl_a[k][:6]) or k not in ('marker contact', 'object contact'), k     # the reference does log them
+            np.testing.assert_allclose(sl_b[k][6:], sl_a[k][6:], rtol=5e-3, atol=2 if k in loss_ref.COUNT_KEYS else 1e-6, err_msg=k)
+        else:
+            np.testing.assert_allclose(sl_b[k][:1], sl_a[k][:1], rtol=1e-6, err_msg=k)
+            np.testing.assert_allclose(sl_b[k], sl_a[k], rtol=5e-3, atol=1e-6, err_msg=k)
+    for k in p_a[-1]:
+        np.testing.assert_allclose(p_b[-1][k].cpu().numpy(), p_a[-1][k].cpu().numpy(), atol=2e-3, err_msg=k)
+    np.testing.assert_allclose(mf_b[0], mf_a[0], atol=2e-4)
