@@ -67,7 +67,8 @@ class FittingOP:
     instead of multiplying the structural zeros of the dense [B,V,3] vertex gradient through the whole mesh; the forward
     is unchanged and the gradients agree to rounding), ``log_gated_terms`` (native path only, default True = the reference:
     stages 1 and 2 evaluate and log the contact / collision terms although their weights are zero there; False: those
-    stages skip the nearest-neighbour search and the hand normals, and ``save_loss`` holds 0 for the gated keys)."""
+    stages skip the nearest-neighbour search and the hand normals and evaluate the body model on the 315 marker / foot
+    vertices only -- nothing else is read there -- and ``save_loss`` holds 0 for the gated keys)."""
 
     def __init__(self, fittingconfig):
         cfg = dict(init_lr_h=0.008, num_iter=[300, 400, 500], batch_size=1, num_markers=143, device='cuda',
@@ -137,6 +138,8 @@ class FittingOP:
         self.foot_markers_all = torch.as_tensor(np.asarray(idx['foot']), dtype=torch.long, device=dev)
         self.rhand_verts_i32 = self.rhand_verts.to(torch.int32)
         self.tables = GraspTables(idx['markers_143'], idx['rhand'], idx['foot'], idx['rhand_weight'], dev)
+        self._idx_np = {k: np.asarray(idx[k]) for k in ('markers_143', 'foot')}
+        self._lite = None
 
     def _make_optimizers(self):
         lr = self.init_lr_h
@@ -358,6 +361,23 @@ class FittingOP:
         t['markers_rec'] = torch.empty(B, self.tables.n_markers, 3, device=self.device)
         return t
 
+    def _lite_handles(self, n_obj):
+        """(model, tables, workspace) of the stages whose contact / collision weights are all zero when ``log_gated_terms`` is
+        off: nothing reads a vertex other than the 143 markers and the 172 foot vertices there, so those stages run the whole
+        iteration on the subset model over them (vertices bit-identical to the full mesh's rows; ``saga_model_create_subset``)."""
+        if self._lite is None or self._lite[0] is not self.bm:
+            mk, ft = self._idx_np['markers_143'], self._idx_np['foot']
+            ids = np.unique(np.concatenate([mk, ft]).astype(np.int64))
+            pos = lambda a: np.searchsorted(ids, a)
+            # the hand tables are not read in these stages; one valid entry keeps the table checks happy
+            tables = GraspTables(pos(mk), pos(mk[:1]), pos(ft), np.ones(1, dtype=np.float32), self.device)
+            self._lite = [self.bm, self.bm.subset_handle(self.device, ids), tables, None]
+        _, model, tables, ws = self._lite
+        n = _lib.load().saga_fit_workspace_floats(model, ctypes.byref(tables.struct), self.batch_size, n_obj)
+        if ws is None or ws.numel() < n:
+            ws = self._lite[3] = torch.zeros(n, device=self.device, dtype=torch.float32)
+        return model, tables, ws
+
     def native_step(self, ss, problem, loss_terms=None):
         """One iteration of stage ``ss`` (loss, backward, Adam update of that stage's variables) in ``saga_fit_step``.
         -> (loss [B], markers_rec [B,143,3]) of BEFORE the update, like the reference's loop body."""
@@ -368,6 +388,13 @@ class FittingOP:
         cfg = _lib.FitStepCfg(ss, int(bool(self.only_rec)), int(self.contact_loss == 'prior'), o['mask'], o['step'],
                               o['lr'], 0.9, 0.999, 1e-8, int(not self.log_gated_terms))
         P = _lib.ptr
+        if not self.log_gated_terms and (ss < 2 or self.only_rec) and self.vertex_subset is None:
+            model, tables, ws = self._lite_handles(problem['struct'].n_obj)
+            _lib.check(_lib.load().saga_fit_step(
+                model, self._native_handles(), ctypes.byref(tables.struct), ctypes.byref(problem['struct']), ctypes.byref(cfg),
+                P(self.vars), P(o['m']), P(o['v']), P(ws), P(problem['loss']), P(loss_terms), P(problem['markers_rec']),
+                self.batch_size, _lib.stream()), 'saga_fit_step')
+            return problem['loss'], problem['markers_rec']
         rest = (self._native_handles(), ctypes.byref(self.tables.struct), ctypes.byref(problem['struct']),
                 ctypes.byref(cfg), P(self.vars), P(o['m']), P(o['v']), P(self._workspace(problem['struct'].n_obj)), P(problem['loss']),
                 P(loss_terms), P(problem['markers_rec']), self.batch_size, _lib.stream())
