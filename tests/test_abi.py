@@ -81,3 +81,17 @@ def test_smplx_create_path_logic_and_dropin_alias(tmp_path):
         smplx.create(str(tmp_path), model_type='smplx', gender='female', ext='npz')
     import chamfer_distance as chd
     assert callable(chd.ChamferDistance)
+
+
+def test_fit_step_cfg_layout_matches_header():
+    """saga_fit_step_cfg_t: five int32, four float, one int32 (skip_gated_terms) -- the ctypes mirror must follow the header."""
+    import ctypes
+    import os
+    import re
+    from saga_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'saga_hip.h')).read()
+    body = re.search(r'typedef struct \{([^}]*)\} saga_fit_step_cfg_t;', hdr).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    names = [n.strip() for decl in body.split(';') if decl.strip() for n in decl.strip().split(None, 1)[1].split(',')]
+    assert names == [f[0] for f in _lib.FitStepCfg._fields_]
+    assert ctypes.sizeof(_lib.FitStepCfg) == 4 * len(names)
