@@ -51,7 +51,7 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // TRS  : accumulate the TRANSPOSED 32x32 tiles (MFMA operands swapped; same products, same order, same bits): a lane then
 //        holds 4 consecutive output columns per register quad and the epilogue is 16 dwordx4 stores per wave instead of
 //        64 dword stores -- the store issue of a 128x128 tile was ~8 % of its time with K = 512
-template <int EPI, int BKT, int NST, int WT = 2, bool TRS = true>
+template <int EPI, int BKT, int NST, int WT = 2, bool TRS = true, bool LEPI = false>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ Bt, int ldb, float* __restrict__ C,
                                                           int ldc, const float* __restrict__ bias,
@@ -184,6 +184,36 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     float* Cz = C;
     if (EPI == 1) Cz += (size_t)slab * M * ldc;
     const bool full = (m0 + TBM <= M);       // N is always a multiple of BN here (Npad / 512)
+    if (TRS && LEPI && EPI == 0 && WT == 2 && full && NST * 2 * TILE_FLOATS >= 4 * 32 * 68) {
+        // whole-line epilogue: the wave's 64 x 64 tile goes through the (now idle) LDS, 32 rows at a time, and leaves as 256-B row
+        // segments (16 lanes x 16 B), non-temporal -- the output then does not displace the operands in L2
+        __syncthreads();
+        float* sw = smem + wave * (32 * 68);
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int mt = 0; mt < WT; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < WT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(sw + l31 * 68 + nt * 32 + 8 * q + 4 * half) =
+                        make_float4(acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]);
+            __builtin_amdgcn_wave_barrier();
+            const int c4 = (lane & 15) * 4;
+            const int col = n0 + wn * 64 + c4;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias) bv = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = it * 4 + (lane >> 4);
+                const float4 v = *reinterpret_cast<const float4*>(sw + r * 68 + c4);
+                const f32x4_t o = {v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w};
+                __builtin_nontemporal_store(o, reinterpret_cast<f32x4_t*>(Cz + (size_t)(m0 + wm * 64 + mt * 32 + r) * ldc + col));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     if (TRS) {
         // transposed tiles: row = lane&31, col = (r&3) + 8*(r>>2) + 4*(lane>>5): one 16-B store per register quad
 #pragma unroll
@@ -253,8 +283,16 @@ int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed
     dim3 grid(tiles_m * tiles_n, 1, 1);
     static const int want_xcd = getenv("SAGA_GEMM_XCD") ? atoi(getenv("SAGA_GEMM_XCD")) : 1;     // SAGA_GEMM_XCD=0: plain tile order (A/B)
     const int xcd_map = want_xcd && tiles_m % 4 == 0 && tiles_n % 2 == 0;
-    gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD><<<grid, 256, 0, st>>>(feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template, nullptr, B, m->Npad,
-                                                FEAT_K, FEAT_K, tiles_m, xcd_map);
+    // whole-line non-temporal epilogue (LEPI, SAGA_GEMM_LEPI=1): the 516 MB of output no longer displaces the operands in L2 -- HBM-side
+    // traffic of the launch 1.14 -> 0.81 GB, same bits -- but the launch is 0.8 % slower and the skinning forward, which then finds
+    // nothing of v_posed in the Infinity Cache, 0.013 ms slower: 4.324 against 4.300 ms per iteration.  Off by default: time wins.
+    static const int want_lepi = getenv("SAGA_GEMM_LEPI") ? atoi(getenv("SAGA_GEMM_LEPI")) : 0;
+    if (want_lepi)
+        gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD, 2, true, true><<<grid, 256, 0, st>>>(feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template,
+                                                                                            nullptr, B, m->Npad, FEAT_K, FEAT_K, tiles_m, xcd_map);
+    else
+        gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD><<<grid, 256, 0, st>>>(feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template, nullptr, B, m->Npad,
+                                                    FEAT_K, FEAT_K, tiles_m, xcd_map);
     SAGA_LAUNCH_CHECK();
     return 0;
 }

@@ -12,6 +12,15 @@ void saga_set_error(const char*, ...) {}
 
 typedef void (*launch_t)(const float*, const float*, float*, const float*, int, int, int, int, hipStream_t);
 
+template <int EPI, int BKT, int NST, bool LEPI, int XCD>
+void launch2(const float* A, const float* Bt, float* C, const float* bias, int M, int N, int K, int splitk, hipStream_t st) {
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
+    const int kchunk = splitk == 1 ? K : ((K + splitk - 1) / splitk + 31) / 32 * 32;
+    dim3 grid(tiles_m * tiles_n, 1, splitk);
+    gemm_nt_f32_kernel<EPI, BKT, NST, 2, true, LEPI><<<grid, 256, 0, st>>>(A, K, Bt, K, C, N, bias, nullptr, M, N, K, kchunk, tiles_m,
+                                                                         splitk == 1 ? XCD : (XCD ? 2 : 0));
+}
+
 template <int EPI, int BKT, int NST, bool TRS = true>
 void launch(const float* A, const float* Bt, float* C, const float* bias, int M, int N, int K, int splitk, hipStream_t st) {
     const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
@@ -41,6 +50,9 @@ int main() {
     Var vars[] = {
         {"st4_dword", launch<0, 16, 4, false>, launch<1, 16, 4, false>},
         {"st4_x4", launch<0, 16, 4, true>, launch<1, 16, 4, true>},
+        {"st4_xcd", launch2<0, 16, 4, false, 1>, launch2<1, 16, 5, false, 1>},
+        {"st4_xcd_lepi", launch2<0, 16, 4, true, 1>, launch2<1, 16, 5, false, 1>},
+        {"st4_lepi", launch2<0, 16, 4, true, 0>, launch2<1, 16, 5, false, 0>},
         {"st5_dword", launch<0, 16, 5, false>, launch<1, 16, 5, false>},
         {"st5_x4", launch<0, 16, 5, true>, launch<1, 16, 5, true>},
         {"st3_x4", launch<0, 16, 3, true>, launch<1, 16, 3, true>},
