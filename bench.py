@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Benchmark of the GraspPose-Opt hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts N ranks itself, one process per GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W           (same ranks under torchrun; --gpus must equal the world size)
+    python bench.py --gpus 8 --batch 2048                  (BASELINE config 3: B = 16,384 = 8 x 2,048 candidates)
 
 One "step" = one fitting iteration of stage 3 (every loss term active) over B candidates on each GPU:
 6D->aa + VPoser decode, SMPL-X forward (full 10,475-vertex mesh), hand vertex normals, two bidirectional
@@ -22,6 +24,8 @@ import sys
 import tempfile
 import time
 
+import hashlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -32,7 +36,8 @@ sys.path.insert(0, ROOT)
 PEAK_F32_TFLOPS = 157.3     # MI355X dense FP32 (vector = matrix), /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (same guide; ~6.3 TB/s achievable)
 V, K_ALG = 10475, 506       # algorithmic K of the blend contraction: 20 shape + 486 pose-feature columns (padded to 512)
-PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'round1_pmc_summary.json')
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'round2_pmc_summary.json')
+GEMM_ENV_FLAGS = ('SAGA_GEMM_LEPI', 'SAGA_GEMM_XCD')
 
 
 def stage_rooflines(prof, steps, B, n_obj, V=10475):
@@ -61,20 +66,44 @@ def stage_rooflines(prof, steps, B, n_obj, V=10475):
     return out
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (separate passes,
-    FETCH_SIZE doubled as the guide prescribes for gfx950); None when the summary is absent."""
+def source_sha16(name):
+    """sha256[:16] of a kernel source file under saga_amd/csrc (what ties a PMC summary to the code it profiled)."""
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, 'saga_amd', 'csrc', name), 'rb').read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def pmc_traffic(B, n_obj, V):
+    """(HBM bytes per launch of the dominant kernel, note).  The PMC counters cannot be collected inside a timed run, so the
+    figure comes from the committed rocprofv3 --pmc summary of THIS command (scripts/profile_round.sh: separate passes,
+    FETCH_SIZE doubled as the guide prescribes for gfx950) -- and only when that summary describes this run: same blend GEMM
+    source (sha256 of blend_gemm.hip recorded in the summary's _meta), same B / O / V, same GEMM environment switches.
+    Otherwise traffic is None and the note says what differed."""
     try:
         d = json.load(open(PMC_SUMMARY))
-        g = [v for k, v in d.items() if k.startswith('gemm_nt_f32_kernel') and v.get('hbm_bytes') and v.get('mean_us', 0) > 500]
-        return round(sum(x['hbm_bytes'] for x in g) / len(g)) if g else None
     except (OSError, ValueError):
-        return None
+        return None, 'no PMC summary at %s' % os.path.relpath(PMC_SUMMARY, ROOT)
+    meta = d.get('_meta') or {}
+    here = {'blend_gemm.hip': source_sha16('blend_gemm.hip'), 'B': B, 'n_obj': n_obj, 'V': V,
+            'env': {k: os.environ.get(k, '') for k in GEMM_ENV_FLAGS}}
+    there = {'blend_gemm.hip': (meta.get('src_sha16') or {}).get('blend_gemm.hip'), 'B': meta.get('B'), 'n_obj': meta.get('n_obj'),
+             'V': meta.get('V'), 'env': {k: (meta.get('env') or {}).get(k, '') for k in GEMM_ENV_FLAGS}}
+    diff = [k for k in here if here[k] != there[k]]
+    if diff:
+        return None, 'PMC summary %s does not describe this run (differs in: %s)' % (os.path.relpath(PMC_SUMMARY, ROOT), ', '.join(diff))
+    g = [v for k, v in d.items() if k.startswith('gemm_nt_f32_kernel') and v.get('hbm_bytes') and v.get('mean_us', 0) > 500]
+    if not g:
+        return None, 'PMC summary holds no blend GEMM launches'
+    return round(sum(x['hbm_bytes'] for x in g) / len(g)), ('offline: %s (git %s), HBM-side bytes per launch, mean of the forward and backward '
+                                                           'launches (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)'
+                                                           % (os.path.relpath(PMC_SUMMARY, ROOT), meta.get('git_head', '?')))
 
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--gpus', type=int, default=None,
+                    help='GPUs (= ranks, one process each) on this node; default: WORLD_SIZE when launched by torchrun, else 1')
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=4096, help='candidates per GPU')
@@ -88,8 +117,8 @@ def parse():
                          'the loss reads (the dense vertex gradient is zero everywhere else)')
     ap.add_argument('--local-weights', action='store_true',
                     help='synthetic skinning weights with mesh-like locality (runs of vertices share their joints); reported separately')
-    ap.add_argument('--cpu-batch', type=int, default=16)
-    ap.add_argument('--cpu-iters', type=int, default=64)
+    ap.add_argument('--cpu-seconds', type=float, default=7.0,
+                    help='CPU baseline: time budget of EACH of its two legs (B=1 reference semantics, B=64 batched)')
     return ap.parse_args()
 
 
@@ -120,8 +149,9 @@ def step(op, d, optimizer=None):
     return loss
 
 
-def cpu_baseline(model_root, vp, n_obj, batch, iters):
-    """The oracle (CPU restatement of the reference iteration, PyTorch eager FP32) timed on the host cores."""
+def cpu_baseline(model_root, vp, n_obj, batch, seconds):
+    """The oracle (CPU restatement of the reference iteration, PyTorch eager FP32) timed on the host cores: as many
+    fwd+bwd iterations at ``batch`` candidates as fit ``seconds`` (at least 2).  -> (candidate-iterations/s, threads, s, iterations)"""
     from oracle import loss_ref, smplx_ref
     from saga_amd.fitting import load_grasp_indices
     from saga_amd.synthetic import make_candidate_params, make_grasp_targets, make_object_cloud
@@ -144,18 +174,30 @@ def cpu_baseline(model_root, vp, n_obj, batch, iters):
         total.sum().backward()
 
     one()                                   # warm-up (allocator, thread pool)
-    t0 = time.perf_counter()
-    for _ in range(iters):
+    iters, t0 = 0, time.perf_counter()
+    while iters < 2 or time.perf_counter() - t0 < seconds:
         one()
+        iters += 1
     dt = time.perf_counter() - t0
-    return batch * iters / dt, threads, dt
+    return batch * iters / dt, threads, dt, iters
 
 
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and (args.gpus or 1) > 1:
+        # plain `python bench.py --gpus N`: start the N ranks here, before anything touches a GPU in this process
+        from saga_amd.launch import launch_ranks
+        try:
+            sys.exit(launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+        except RuntimeError as e:
+            sys.exit('bench.py: %s' % e)
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if args.gpus is not None and args.gpus != world:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d: launch as many ranks as GPUs (or drop --gpus under torchrun)' % (args.gpus, world))
+    if torch.cuda.device_count() <= local:
+        sys.exit('bench.py: rank %d needs GPU %d, but %d GPU(s) are visible' % (rank, local, torch.cuda.device_count()))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
@@ -208,7 +250,7 @@ def main():
     # end-of-fit exchange (untimed): all-gather (loss, parameters) of every candidate, best-of-N per group of 8
     with torch.no_grad():
         params = {k: v.detach().reshape(B, -1) for k, v in op.body_params().items()}
-    gl, gp = gather_candidates(loss.detach(), params, n_total=B * world)
+    gl, gp = gather_candidates(loss.detach(), params, n_total=B * world, force_collective=world == 1 and bool(os.environ.get('SAGA_BENCH_RCCL')))
     _, best_loss, _ = best_of_n(gl, gp, group_size=8)
 
     if rank == 0:
@@ -248,10 +290,13 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_f32_kernel (blend contraction, fwd+bwd launches)',
                          'achieved': None if achieved is None else round(achieved, 2), 'peak': PEAK_F32_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': None if achieved is None else round(achieved / PEAK_F32_TFLOPS, 4),
-                         'traffic': None if (args.loss_vertices_only or args.sparse_backward) else pmc_traffic(),
-                         'traffic_note': 'HBM-side bytes per launch, mean of the forward and backward launches (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/); '
-                                         'algorithmic bytes per launch = %d' % int(B * 3 * V_eval * 4 + B * 512 * 4 + 3 * V_eval * 512 * 4)},
+                         'traffic': None, 'traffic_source': None,
+                         'algorithmic_bytes': int(B * 3 * V_eval * 4 + B * 512 * 4 + 3 * V_eval * 512 * 4)},
         }
+        if args.loss_vertices_only or args.sparse_backward or args.local_weights or args.autograd:
+            out['roofline']['traffic_source'] = 'not profiled for this variant'
+        else:
+            out['roofline']['traffic'], out['roofline']['traffic_source'] = pmc_traffic(B, n_obj, V_eval)
         if args.sparse_backward:        # the dense algorithmic figures do not describe this variant's backward kernels
             for k in ('blend_gemm_bwd', 'skin_bwd', 'grasp_loss_bwd'):
                 out['config']['stages'].pop(k, None)
@@ -260,12 +305,18 @@ def main():
                 'bench.py --sparse-backward (saga_fit_step_sparse: same full-mesh forward, backward over the loss vertices only; '
                 'profiles/round1_k_sparse_backward_bench.json: 2.9-3.0 ms per iteration) and --loss-vertices-only; never the headline')
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only (host cores are shared by the ranks)
-            cand_per_s, threads, dt = cpu_baseline(tmp.name, vp, n_obj, args.cpu_batch, args.cpu_iters)
+            # the oracle at B=1 (the reference's own semantics: one candidate at a time) AND at B=64 (batched, to be
+            # fair to the CPU); value = the better of the two
+            legs = []
+            for cb in (1, 64):
+                cand_per_s, threads, dt, iters = cpu_baseline(tmp.name, vp, n_obj, cb, args.cpu_seconds)
+                legs.append((cand_per_s, 'B=%d: %d fwd+bwd iterations in %.1f s = %.2f candidate-iterations/s' % (cb, iters, dt, cand_per_s)))
+            best = max(l[0] for l in legs)
             out['cpu_baseline'] = {
-                'value': round(cand_per_s / B, 6), 'unit': 'iterations/s at B=%d (extrapolated from candidate-iterations/s)' % B,
+                'value': round(best / B, 6), 'unit': 'iterations/s at B=%d (extrapolated from candidate-iterations/s)' % B,
                 'cores': threads, 'kind': 'port',
-                'sample': '%d fwd+bwd iterations of the oracle at B=%d candidates x %d object points (%.1f s), '
-                          '%.2f candidate-iterations/s' % (args.cpu_iters, args.cpu_batch, n_obj, dt, cand_per_s)}
+                'sample': 'oracle (PyTorch CPU eager FP32, %d threads) on the same workload, %d object points; %s; %s; value = the better leg'
+                          % (threads, n_obj, legs[0][1], legs[1][1])}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -30,7 +30,10 @@ def init_vars(B, hand_ncomps=24, dtype=torch.float32):
 def fitting(bm, vposer_w, idx, body_markers, object_contact, markers_contact, verts_object,
             normal_object, num_iter=(300, 400, 500), init_lr_h=0.008, var=None,
             only_rec=False, contact_loss='contact', hand_ncomps=24, record=None):
-    """-> (smplxparams_list[3], markers_fit_list[3], loss_history[list of [B] tensors])."""
+    """-> (smplxparams_list[3], markers_fit_list[3], loss_history[list of [B] tensors]).
+
+    ``record(ss, ii, loss_dict, counts, snapshot_fn, markers_rec)`` is called after every ``step()``: ``snapshot_fn()`` gives
+    the SMPL-X parameter dict of the variables as they are then (after the update); ``markers_rec`` is from before it."""
     B = body_markers.shape[0]
     var = init_vars(B, hand_ncomps, body_markers.dtype) if var is None else var
     opts = [
@@ -59,7 +62,7 @@ def fitting(bm, vposer_w, idx, body_markers, object_contact, markers_contact, ve
             opt.step()
             history.append(total.detach().clone())
             if record is not None:
-                record(ss, ii, ld, cnt)
+                record(ss, ii, ld, cnt, snapshot, aux['markers_rec'].detach())
             if not only_rec and ss == 2 and ii > 200:                                   # :430
                 better = total.detach() < best
                 if better.any():
@@ -74,9 +77,12 @@ def fitting(bm, vposer_w, idx, body_markers, object_contact, markers_contact, ve
                     best = torch.where(better, total.detach(), best)
         last_of_stage3 = (ss == 2 and not only_rec and best_params is not None and num_iter[2] > 0)
         if last_of_stage3:
-            # early_stop is set on the last iteration of stage 3 (:458-460) -> tmp params kept (:486)
-            params_list.append(copy.deepcopy(best_params))
-            markers_list.append(best_markers.clone())
+            # early_stop is set on the last iteration of stage 3 (:458-460) -> tmp params kept (:486); a candidate whose
+            # loss never went below 10000 has tmp_info None at batch size 1 and keeps its final state (:464)
+            never = best >= 10000.0
+            final, mk_final = snapshot(), aux['markers_rec'].detach()
+            params_list.append({k: torch.where(never.view(-1, *[1] * (v.dim() - 1)), final[k], v) for k, v in best_params.items()})
+            markers_list.append(torch.where(never[:, None, None], mk_final, best_markers))
         else:
             params_list.append(snapshot())                                              # :466-475
             markers_list.append(aux['markers_rec'].detach().clone())

@@ -155,11 +155,28 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream(device=None):
+    """hipStream_t of torch's current stream ON ``device`` (default: the current device)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def call(name, device, *args):
+    """Run entry point ``name`` with ``device`` current and torch's current stream of THAT device appended as the last
+    argument -- the kernels launch where the tensors live, whatever the process's current device is (the library checks
+    its model / decoder handles against the current device and returns SAGA_EINVAL on a mismatch)."""
+    device = torch.device(device)
+    if device.type != 'cuda':
+        raise RuntimeError('saga_amd ops run on the GPU only (device %s); there is no CPU fallback' % device)
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    fn = getattr(load(), name)
+    with torch.cuda.device(device):
+        check(fn(*args, stream(device)), name)
 
 
 def require_device(*tensors):
+    """Every tensor on ONE ROCm device, float32 / int32; -> that device."""
+    dev = None
     for t in tensors:
         if t is None:
             continue
@@ -167,6 +184,11 @@ def require_device(*tensors):
             raise RuntimeError('saga_amd ops run on the GPU only (got a %s tensor); there is no CPU fallback' % t.device)
         if t.dtype not in (torch.float32, torch.int32):
             raise TypeError('saga_amd ops take float32 / int32 tensors, got %s' % t.dtype)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError('saga_amd ops take tensors of one device, got %s and %s' % (dev, t.device))
+    return dev
 
 
 def profile_enable(on=True):

@@ -20,8 +20,8 @@ class _ChamferFn(torch.autograd.Function):
         idx1 = torch.empty(N, P1, device=dev, dtype=torch.int32)
         idx2 = torch.empty(N, P2, device=dev, dtype=torch.int32)
         lib = _lib.load()
-        _lib.check(lib.saga_chamfer_fwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(dist1), _lib.ptr(dist2), _lib.ptr(idx1),
-                                        _lib.ptr(idx2), N, P1, P2, _lib.stream()), 'saga_chamfer_fwd')
+        _lib.call('saga_chamfer_fwd', x.device, _lib.ptr(x), _lib.ptr(y), _lib.ptr(dist1), _lib.ptr(dist2), _lib.ptr(idx1),
+                                        _lib.ptr(idx2), N, P1, P2)
         ctx.save_for_backward(x, y, idx1, idx2)
         ctx.mark_non_differentiable(idx1, idx2)
         ctx.set_materialize_grads(False)
@@ -39,8 +39,8 @@ class _ChamferFn(torch.autograd.Function):
         g1 = None if g1 is None else g1.contiguous()
         g2 = None if g2 is None else g2.contiguous()
         lib = _lib.load()
-        _lib.check(lib.saga_chamfer_bwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(idx1), _lib.ptr(idx2), _lib.ptr(g1),
-                                        _lib.ptr(g2), _lib.ptr(gx), _lib.ptr(gy), N, P1, P2, _lib.stream()), 'saga_chamfer_bwd')
+        _lib.call('saga_chamfer_bwd', x.device, _lib.ptr(x), _lib.ptr(y), _lib.ptr(idx1), _lib.ptr(idx2), _lib.ptr(g1),
+                                        _lib.ptr(g2), _lib.ptr(gx), _lib.ptr(gy), N, P1, P2)
         return gx, gy
 
 
@@ -56,8 +56,7 @@ def chamfer_nn(x, y):
     idx1 = torch.empty(N, P1, device=x.device, dtype=torch.int32)
     idx2 = torch.empty(N, P2, device=x.device, dtype=torch.int32)
     lib = _lib.load()
-    _lib.check(lib.saga_chamfer_fwd(_lib.ptr(x), _lib.ptr(y), None, None, _lib.ptr(idx1), _lib.ptr(idx2), N, P1, P2,
-                                    _lib.stream()), 'saga_chamfer_fwd')
+    _lib.call('saga_chamfer_fwd', x.device, _lib.ptr(x), _lib.ptr(y), None, None, _lib.ptr(idx1), _lib.ptr(idx2), N, P1, P2)
     return idx1, idx2
 
 

@@ -112,6 +112,7 @@ struct FitWs {
     float *g_verts, *gvp, *slab, *dA, *g_shape, *g_pose, *g_transl;       // SMPL-X backward
     float *g_x6, *g_h, *g_z, *grad;                                       // reverse parameter maps
     int32_t* zero_tag;                                                    // [B] rows of g_verts already zero outside the touched vertices
+    int32_t* hdr;                                                         // word 0: layout hash of the last saga_fit_step on this workspace
     size_t total;
 };
 
@@ -126,6 +127,7 @@ static FitWs fit_ws_carve(float* base, const saga_model* m, const saga_grasp_tab
     const size_t b = (size_t)B;
     const int M = tb ? tb->n_markers : 0, H = tb ? tb->n_hand : 0;
     const int V = m ? m->V : 0, Npad = m ? m->Npad : 0, S = m ? m->S : 0, njo = m ? NJ + m->E + m->L : 0;
+    w.hdr = (int32_t*)take(64);          // first, so that every layout of one workspace finds it at the same address
     w.h1 = take(b * hidden); w.h2 = take(b * hidden); w.x6 = take(b * X6_LD); w.jac = take(b * (NB_MAX + 1) * 18);
     w.shape = take(b * (S > 0 ? S : 1)); w.full_pose = take(b * 165); w.transl = take(b * 3);
     w.feat = take(b * FEAT_K); w.rot = take(b * NJ * 9); w.jrest = take(b * NJ * 3); w.chain = take(b * NJ * 12);
@@ -171,8 +173,9 @@ __global__ __launch_bounds__(PK_THREADS) void params_fwd_kernel(const float* __r
                                                                 const float* __restrict__ pose_mean, float* __restrict__ full_pose,
                                                                 float* __restrict__ shape, float* __restrict__ transl,
                                                                 float* __restrict__ jac, float* __restrict__ body_params, int S,
-                                                                int n_pca) {
+                                                                int n_pca, int32_t* __restrict__ hdr_clear) {
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (hdr_clear && b == 0 && tid == 126) hdr_clear[0] = 0;      // saga_fit_decode: this workspace's last layout is void
     const float* v = vars + (size_t)b * VS;
     float* fp = full_pose ? full_pose + (size_t)b * 165 : nullptr;
     float* bp = body_params ? body_params + (size_t)b * SAGA_BODY_PARAM_COUNT : nullptr;
@@ -229,10 +232,14 @@ __global__ __launch_bounds__(PK_THREADS) void params_fwd_kernel(const float* __r
 struct LossCfg { int stage, only_rec, prior; };
 
 // weighted sum of fittingop.py:215-223 (same order of additions) + the gradient of it w.r.t. the eight fused terms
+// Also the workspace's layout check: when the last saga_fit_step on this workspace carved it differently (another B, O,
+// mesh or table set), that call wrote into what is g_verts now, so every "row already zero" mark of this layout is void.
 __global__ void loss_sum_kernel(const float* __restrict__ terms, const float* __restrict__ vars, LossCfg cfg,
-                                float* __restrict__ g_terms, float* __restrict__ loss, float* __restrict__ out, int B) {
+                                float* __restrict__ g_terms, float* __restrict__ loss, float* __restrict__ out, int B,
+                                const int32_t* __restrict__ hdr, int32_t layout, int32_t* __restrict__ zero_tag) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    if (hdr[0] != layout) zero_tag[b] = 0;
     const float* t = terms + (size_t)b * NTERM;
     const float* v = vars + (size_t)b * VS;
     float sv = 0.f, sh = 0.f, se = 0.f;
@@ -319,10 +326,14 @@ __device__ __forceinline__ int var_group(int col) {
 
 // torch.optim.Adam (no amsgrad, no weight decay): exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*v + (1-b2) g g;
 // denom = sqrt(v) / sqrt(1 - b2^t) + eps; p -= lr / (1 - b1^t) * m / denom
+// Last kernel of an iteration: it also records the layout this iteration carved the workspace with (read by the next
+// call's loss_sum_kernel; every block of that kernel has finished before this one starts).
 __global__ void adam_kernel(float* __restrict__ vars, float* __restrict__ m, float* __restrict__ vv,
-                            const float* __restrict__ grad, const float* __restrict__ g_z, AdamCfg c, int B) {
+                            const float* __restrict__ grad, const float* __restrict__ g_z, AdamCfg c, int B,
+                            int32_t* __restrict__ hdr, int32_t layout) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * SAGA_VAR_COUNT) return;
+    if (i == 0) hdr[0] = layout;
     const int b = i / SAGA_VAR_COUNT, col = i % SAGA_VAR_COUNT;
     if (!(var_group(col) & c.mask)) return;
     const size_t o = (size_t)b * VS + col;
@@ -374,6 +385,7 @@ static int decoder_fwd(const saga_decoder* d, const float* vars, const FitWs& w,
 
 extern "C" int saga_fit_decode(const saga_decoder_t* d, const float* vars, float* body_params, float* ws, int B, void* stream) {
     SAGA_CHECK_ARG(d && vars && body_params && ws, "saga_fit_decode: null argument");
+    SAGA_CHECK_DEVICE(d, "saga_fit_decode");
     SAGA_CHECK_ARG(B >= 0 && B <= 65535 && d->hidden <= 512, "saga_fit_decode: bad sizes");
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -381,7 +393,7 @@ extern "C" int saga_fit_decode(const saga_decoder_t* d, const float* vars, float
     int rc;
     if ((rc = decoder_fwd(d, vars, w, B, st))) return rc;
     params_fwd_kernel<<<B, PK_THREADS, 0, st>>>(vars, w.x6, d->hand_comp, d->pose_mean, nullptr, nullptr, nullptr, nullptr, body_params,
-                                                0, d->n_pca);
+                                                0, d->n_pca, w.hdr);
     SAGA_LAUNCH_CHECK();
     return 0;
 }
@@ -402,6 +414,8 @@ static int fit_step_impl(const saga_model_t* m, const saga_model_t* mb, const sa
                          float* adam_v, float* ws, float* loss, float* loss_terms, float* markers_rec, int B, void* stream) {
     SAGA_CHECK_ARG(m && d && tb && prob && cfg && vars && adam_m && adam_v && ws && loss && markers_rec,
                    "saga_fit_step: null argument");
+    SAGA_CHECK_DEVICE(m, "saga_fit_step (model)");
+    SAGA_CHECK_DEVICE(d, "saga_fit_step (decoder)");
     SAGA_CHECK_ARG(B >= 0 && B <= 65535, "saga_fit_step: batch %d outside [0, 65535]", B);
     SAGA_CHECK_ARG(d->hidden <= 512, "saga_fit_step: decoder hidden size %d > 512", d->hidden);
     SAGA_CHECK_ARG(m->S >= 10 || m->S == 0, "saga_fit_step: model has %d shape coefficients (< 10 betas)", m->S);
@@ -421,12 +435,20 @@ static int fit_step_impl(const saga_model_t* m, const saga_model_t* mb, const sa
     hipStream_t st = (hipStream_t)stream;
     const int O = prob->n_obj;
     FitWs w = fit_ws_carve(ws, m, tb, 512, B, O);
+    // what the carve above depends on (+ the table set the zero-fill marks are for); never 0, the value a fresh workspace holds
+    uint64_t lh = 0xCBF29CE484222325ull;
+    for (uint64_t x : {(uint64_t)B, (uint64_t)O, (uint64_t)m->V, (uint64_t)m->Npad, (uint64_t)m->S, (uint64_t)(m->E + m->L),
+                       (uint64_t)tb->n_markers, (uint64_t)tb->n_hand, (uint64_t)tb->n_unique, (uint64_t)(uintptr_t)tb->unique_ids,
+                       (uint64_t)(uintptr_t)ws})
+        lh = (lh ^ x) * 0x100000001B3ull;
+    int32_t layout = (int32_t)(lh ^ (lh >> 32));
+    if (layout == 0) layout = 1;
     int rc;
     {   // optimiser variables -> shape / full_pose / transl
         Prof p(SAGA_PROF_PARAMS_FWD, stream);
         if ((rc = decoder_fwd(d, vars, w, B, st))) return rc;
         params_fwd_kernel<<<B, PK_THREADS, 0, st>>>(vars, w.x6, d->hand_comp, d->pose_mean, w.full_pose, w.shape, w.transl, w.jac,
-                                                    nullptr, m->S, d->n_pca);
+                                                    nullptr, m->S, d->n_pca, nullptr);
         SAGA_LAUNCH_CHECK();
     }
     // sparse backward: the skinning forward also writes the v_posed rows of the loss vertices, compact, for the subset backward
@@ -446,7 +468,7 @@ static int fit_step_impl(const saga_model_t* m, const saga_model_t* mb, const sa
     {
         Prof p(SAGA_PROF_LOSS_SUM, stream);
         LossCfg lc{cfg->stage, cfg->only_rec, cfg->prior_contact};
-        loss_sum_kernel<<<(B + 127) / 128, 128, 0, st>>>(w.terms, vars, lc, w.g_terms, loss, loss_terms, B);
+        loss_sum_kernel<<<(B + 127) / 128, 128, 0, st>>>(w.terms, vars, lc, w.g_terms, loss, loss_terms, B, w.hdr, layout, w.zero_tag);
         SAGA_LAUNCH_CHECK();
     }
     if (mb) {
@@ -467,7 +489,8 @@ static int fit_step_impl(const saga_model_t* m, const saga_model_t* mb, const sa
     } else {
         // the dense gradient rows of the workspace are zero-filled once: every call rewrites the same (tables') vertices.
         // The tag ties the "already zero" mark to this table set, mesh and workspace address; it is never 0, so a
-        // zero-initialised workspace (the contract) always fills on first use.
+        // zero-initialised workspace (the contract) always fills on first use.  A call that carved the workspace differently
+        // in between (another B / O / mesh) has had its marks cleared by loss_sum_kernel above (header word != layout).
         uint64_t h = (uint64_t)(uintptr_t)tb->unique_ids * 0x9E3779B97F4A7C15ull ^ (uint64_t)(uintptr_t)w.g_verts * 0xC2B2AE3D27D4EB4Full ^
                      ((uint64_t)tb->n_unique << 32) ^ (uint64_t)m->V;
         int32_t tag = (int32_t)(h ^ (h >> 32));
@@ -503,7 +526,7 @@ static int fit_step_impl(const saga_model_t* m, const saga_model_t* mb, const sa
         const double bc2 = 1.0 - pow((double)cfg->beta2, (double)cfg->adam_step);
         AdamCfg ac{cfg->update_mask, cfg->stage, (float)((double)cfg->lr / bc1), cfg->beta1, cfg->beta2, (float)sqrt(bc2), cfg->eps};
         const int n = B * SAGA_VAR_COUNT;
-        adam_kernel<<<(n + 255) / 256, 256, 0, st>>>(vars, adam_m, adam_v, w.grad, w.g_z, ac, B);
+        adam_kernel<<<(n + 255) / 256, 256, 0, st>>>(vars, adam_m, adam_v, w.grad, w.g_z, ac, B, w.hdr, layout);
         SAGA_LAUNCH_CHECK();
     }
     return 0;

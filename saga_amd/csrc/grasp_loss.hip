@@ -625,6 +625,7 @@ extern "C" int saga_grasp_loss_fwd(const saga_model_t* m, const saga_grasp_table
                                    float* hand_normals, float* h2o_marker, float* h2o_signed, float* o2h_signed,
                                    int32_t* idx_m2o, int32_t* idx_h2o, int32_t* idx_o2h, int B, int O, void* stream) {
     SAGA_CHECK_ARG(m && m->F > 0, "saga_grasp_loss_fwd: model without faces");
+    SAGA_CHECK_DEVICE(m, "saga_grasp_loss_fwd");
     int rc = check_tables(tb);
     if (rc) return rc;
     SAGA_CHECK_ARG(B >= 0 && O > 0, "saga_grasp_loss_fwd: bad sizes B=%d O=%d", B, O);
@@ -652,6 +653,7 @@ extern "C" int saga_grasp_loss_fwd(const saga_model_t* m, const saga_grasp_table
 int saga_grasp_loss_fwd_rec(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* verts, const float* markers_target,
                             float* terms, float* markers_rec, int32_t* idx_m2o, int B, void* stream) {
     SAGA_CHECK_ARG(m && idx_m2o, "saga_grasp_loss_fwd_rec: null model");
+    SAGA_CHECK_DEVICE(m, "saga_grasp_loss_fwd_rec");
     int rc = check_tables(tb);
     if (rc) return rc;
     SAGA_CHECK_ARG(B >= 0 && verts && markers_target && terms && markers_rec, "saga_grasp_loss_fwd_rec: bad arguments");
@@ -685,6 +687,7 @@ int saga_grasp_loss_bwd_tagged(const saga_model_t* m, const saga_grasp_tables_t*
                                const float* o2h_signed, const int32_t* idx_m2o, const int32_t* idx_h2o,
                                const int32_t* idx_o2h, float* g_verts, int B, int O, int32_t* zero_tag, int32_t tag, int compact, void* stream) {
     SAGA_CHECK_ARG(m, "saga_grasp_loss_bwd: null model");
+    SAGA_CHECK_DEVICE(m, "saga_grasp_loss_bwd");
     int rc = check_tables(tb);
     if (rc) return rc;
     SAGA_CHECK_ARG(B >= 0 && O > 0, "saga_grasp_loss_bwd: bad sizes B=%d O=%d", B, O);

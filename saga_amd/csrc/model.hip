@@ -17,6 +17,14 @@ void saga_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* saga_last_error(void) { return g_err; }
+
+int saga_check_device(int device, const char* what) {
+    int cur = -1;
+    SAGA_HIP(hipGetDevice(&cur));
+    SAGA_CHECK_ARG(cur == device, "%s: the handle's constants live on device %d but the current device is %d "
+                   "(make that device current -- hipSetDevice / torch.cuda.device -- and pass one of its streams)", what, device, cur);
+    return 0;
+}
 extern "C" int saga_version(void) { return 100; }
 
 template <typename T>

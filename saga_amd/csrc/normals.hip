@@ -26,6 +26,7 @@ __global__ void vertex_normals_kernel(const float* __restrict__ verts, const int
 
 static int launch(const saga_model_t* m, const float* verts, const int32_t* sel, int n_out, float* normals, int B, void* stream) {
     SAGA_CHECK_ARG(m && m->F > 0, "saga_vertex_normals: model has no faces");
+    SAGA_CHECK_DEVICE(m, "saga_vertex_normals");
     SAGA_CHECK_ARG(B >= 0 && B <= 65535 && n_out >= 0, "saga_vertex_normals: bad sizes B=%d n=%d", B, n_out);
     if (B == 0 || n_out == 0) return 0;
     SAGA_CHECK_ARG(verts && normals, "saga_vertex_normals: null argument");

@@ -18,6 +18,14 @@
 #define WT_COLS 64              // dense weight table padded to 64 columns for the MFMA dA reduction
 
 void saga_set_error(const char* fmt, ...);
+// 0 when `device` (where a model / decoder handle's constants live) is the calling thread's current HIP device, else
+// SAGA_EINVAL: the kernels would otherwise launch on another GPU with this one's pointers
+int saga_check_device(int device, const char* what);
+#define SAGA_CHECK_DEVICE(handle, what)                                   \
+    do {                                                                  \
+        int rc_dev_ = saga_check_device((handle)->device, what);          \
+        if (rc_dev_) return rc_dev_;                                      \
+    } while (0)
 
 #define SAGA_CHECK_ARG(cond, ...)                      \
     do {                                               \

@@ -87,6 +87,7 @@ int saga_smplx_fwd_sel(const saga_model_t* m, const saga_model_t* sub, const flo
                        float* vertices, float* joints, float* feat, float* rot, float* jrest, float* chain, float* A, float* v_posed,
                        float* sel_rows, int B, void* stream) {
     SAGA_CHECK_ARG(m, "saga_smplx_fwd: null model");
+    SAGA_CHECK_DEVICE(m, "saga_smplx_fwd");
     SAGA_CHECK_ARG(B >= 0 && B <= 65535, "saga_smplx_fwd: batch %d outside [0, 65535]", B);
     if (B == 0) return 0;
     SAGA_CHECK_ARG(full_pose && vertices && feat && rot && jrest && chain && A && v_posed && (m->S == 0 || shape),
@@ -110,6 +111,7 @@ extern "C" int saga_smplx_bwd(const saga_model_t* m, const float* g_vertices, co
                               float* g_shape, float* g_full_pose, float* g_transl, float* ws_gvp, float* ws_slab, float* ws_dA,
                               float* ws_gv, int B, void* stream) {
     SAGA_CHECK_ARG(m, "saga_smplx_bwd: null model");
+    SAGA_CHECK_DEVICE(m, "saga_smplx_bwd");
     SAGA_CHECK_ARG(B >= 0 && B <= 65535, "saga_smplx_bwd: batch %d outside [0, 65535]", B);
     if (B == 0) return 0;
     SAGA_CHECK_ARG(g_vertices || g_joints, "saga_smplx_bwd: no incoming gradient");

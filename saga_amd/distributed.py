@@ -35,27 +35,39 @@ def unpack(buf, dims):
     return losses, out
 
 
-def gather_candidates(losses, params, n_total=None, group=None):
-    """All-gather every rank's candidates.  Returns (losses [N], params dict [N,.]) in global candidate order.
-    Works without an initialised process group (single process: returns the inputs)."""
+def gather_candidates(losses, params, n_total=None, group=None, force_collective=False):
+    """All-gather every rank's candidates.  Returns (losses [N], params dict [N,.]) in global candidate order (rank order;
+    within a rank, row order).  Shards may be ragged: the per-rank row counts are exchanged first (one tiny all-gather),
+    rows are padded to the largest shard for the single ``all_gather_into_tensor`` and the padding is cut out again.
+    ``n_total`` (optional) is checked against the gathered counts, and this rank's rows against its ``shard_range``.
+    Works without an initialised process group (single process: returns the inputs); ``force_collective`` runs the
+    collectives even in a group of one rank (exercises the RCCL path on a 1-GPU box)."""
     dims = {k: int(params[k].reshape(losses.shape[0], -1).shape[1]) for k in PARAM_ORDER}
     buf = pack(losses, params)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    ready = dist.is_available() and dist.is_initialized()
+    if not ready or (dist.get_world_size(group) == 1 and not force_collective):
+        if n_total is not None and (not ready or dist.get_world_size(group) == 1) and n_total != buf.shape[0]:
+            raise ValueError('gather_candidates: %d rows on the only rank, n_total = %d' % (buf.shape[0], n_total))
         return unpack(buf, dims)
-    world = dist.get_world_size(group)
-    counts = [shard_range(n_total, r, world) for r in range(world)] if n_total is not None else None
-    if counts is not None and len({e - s for s, e in counts}) > 1:
-        # ragged shards: pad to the largest so a single all_gather_into_tensor still applies
-        mx = max(e - s for s, e in counts)
-        pad = torch.zeros(mx - buf.shape[0], buf.shape[1], device=buf.device, dtype=buf.dtype)
-        send = torch.cat([buf, pad], 0)
-    else:
-        mx = buf.shape[0]
-        send = buf
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = torch.tensor([buf.shape[0]], device=buf.device, dtype=torch.int64)
+    counts_t = torch.empty(world, device=buf.device, dtype=torch.int64)
+    dist.all_gather_into_tensor(counts_t, mine, group=group)
+    counts = [int(c) for c in counts_t.tolist()]
+    if n_total is not None:
+        if sum(counts) != n_total:
+            raise ValueError('gather_candidates: the ranks hold %s rows, n_total = %d' % (counts, n_total))
+        s, e = shard_range(n_total, rank, world)
+        if e - s != buf.shape[0]:
+            raise ValueError('gather_candidates: rank %d holds %d rows, its shard of %d is %d' % (rank, buf.shape[0], n_total, e - s))
+    mx = max(counts)
+    send = buf
+    if buf.shape[0] < mx:
+        send = torch.cat([buf, torch.zeros(mx - buf.shape[0], buf.shape[1], device=buf.device, dtype=buf.dtype)], 0)
     recv = torch.empty(world * mx, buf.shape[1], device=buf.device, dtype=buf.dtype)
     dist.all_gather_into_tensor(recv, send, group=group)
-    if counts is not None and mx * world != (n_total or 0):
-        recv = torch.cat([recv[r * mx:r * mx + (e - s)] for r, (s, e) in enumerate(counts)], 0)
+    if any(c != mx for c in counts):
+        recv = torch.cat([recv[r * mx:r * mx + c] for r, c in enumerate(counts)], 0)
     return unpack(recv, dims)
 
 

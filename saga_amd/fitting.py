@@ -173,8 +173,11 @@ class FittingOP:
             self.betas.copy_(torch.as_tensor(betas, dtype=torch.float32, device=self.device).reshape(1, -1).expand_as(self.betas))
 
     def reset(self):
-        """fittingop.py:129-135 (the reference keeps its Adam moments across samples; here a fresh batch gets
-        fresh optimisers, which is what a first call sees)."""
+        """fittingop.py:129-135.  DELIBERATE difference: the reference builds its three Adam optimisers once
+        (:77-84) and ``reset()`` only re-initialises the variables, so the exp_avg / exp_avg_sq moments and step counts
+        of sample k leak into sample k+1 (an artefact of looping over samples at batch size 1).  Here the
+        candidates of a batch are independent problems and every batch starts from fresh optimisers -- what the
+        reference's FIRST sample sees, and what makes a candidate's result independent of the batch it is in."""
         with torch.no_grad():
             for t in (self.betas, self.transl_rec, self.vpose_rec, self.hand_pose, self.eye_pose):
                 t.zero_()
@@ -390,22 +393,22 @@ class FittingOP:
         P = _lib.ptr
         if not self.log_gated_terms and (ss < 2 or self.only_rec) and self.vertex_subset is None:
             model, tables, ws = self._lite_handles(problem['struct'].n_obj)
-            _lib.check(_lib.load().saga_fit_step(
-                model, self._native_handles(), ctypes.byref(tables.struct), ctypes.byref(problem['struct']), ctypes.byref(cfg),
-                P(self.vars), P(o['m']), P(o['v']), P(ws), P(problem['loss']), P(loss_terms), P(problem['markers_rec']),
-                self.batch_size, _lib.stream()), 'saga_fit_step')
+            _lib.call('saga_fit_step', self.device,
+                      model, self._native_handles(), ctypes.byref(tables.struct), ctypes.byref(problem['struct']), ctypes.byref(cfg),
+                      P(self.vars), P(o['m']), P(o['v']), P(ws), P(problem['loss']), P(loss_terms), P(problem['markers_rec']),
+                      self.batch_size)
             return problem['loss'], problem['markers_rec']
         rest = (self._native_handles(), ctypes.byref(self.tables.struct), ctypes.byref(problem['struct']),
                 ctypes.byref(cfg), P(self.vars), P(o['m']), P(o['v']), P(self._workspace(problem['struct'].n_obj)), P(problem['loss']),
-                P(loss_terms), P(problem['markers_rec']), self.batch_size, _lib.stream())
+                P(loss_terms), P(problem['markers_rec']), self.batch_size)
         if self.sparse_backward:
             cached = getattr(self, '_m_loss', None)
             if cached is None or cached[0] is not self.bm:       # subset model of the current body model, looked up once
                 cached = self._m_loss = (self.bm, self.bm.subset_handle(self.device, self.tables.unique_ids_host))
             m_loss = cached[1]
-            _lib.check(_lib.load().saga_fit_step_sparse(self.bm.handle(self.device), m_loss, *rest), 'saga_fit_step_sparse')
+            _lib.call('saga_fit_step_sparse', self.device, self.bm.handle(self.device), m_loss, *rest)
         else:
-            _lib.check(_lib.load().saga_fit_step(self.bm.handle(self.device), *rest), 'saga_fit_step')
+            _lib.call('saga_fit_step', self.device, self.bm.handle(self.device), *rest)
         return problem['loss'], problem['markers_rec']
 
     def workspace_view(self, name, n_obj, shape, dtype=torch.float32):
@@ -425,8 +428,7 @@ class FittingOP:
         out = torch.empty(B, _lib.BODY_PARAM_COUNT, device=self.device)
         n = _lib.load().saga_fit_workspace_floats(self.bm.handle(self.device), ctypes.byref(self.tables.struct), B, 1)
         ws = self._ws if (self._ws is not None and self._ws.numel() >= n) else torch.empty(n, device=self.device)
-        _lib.check(_lib.load().saga_fit_decode(self._native_handles(), _lib.ptr(packed), _lib.ptr(out), _lib.ptr(ws), B,
-                                               _lib.stream()), 'saga_fit_decode')
+        _lib.call('saga_fit_decode', self.device, self._native_handles(), _lib.ptr(packed), _lib.ptr(out), _lib.ptr(ws), B)
         return {k: out[:, a:b].clone() for k, (a, b) in _lib.BODY_PARAM_SLICES.items()}
 
     def _fitting_native(self, body_markers, object_contact, markers_contact, verts_object, normal_object):
@@ -449,16 +451,19 @@ class FittingOP:
                 if self.verbose and ii % 100 == 99:
                     self.logger('[INFO][fitting][stage%d] iter=%d, mean loss %.5f' % (ss, ii, float(loss.mean())))
                 if not self.only_rec and ss == 2 and ii > 200:
-                    _lib.check(lib.saga_fit_best_update(P(loss), P(self.vars), P(mk), P(best_loss), P(best_vars), P(best_markers),
-                                                        B, M, _lib.stream()), 'saga_fit_best_update')
+                    _lib.call('saga_fit_best_update', self.device, P(loss), P(self.vars), P(mk), P(best_loss), P(best_vars),
+                              P(best_markers), B, M)
                     any_best = True
             has_iter = self.num_iter[ss] > 0
             if ss == 2 and any_best:
                 never = best_loss >= 10000.0           # such a candidate keeps its final parameters (tmp_info is None, :464)
                 out = self.decode_vars(torch.where(never[:, None], self.vars, best_vars))
                 mfit = torch.where(never[:, None, None], prob['markers_rec'], best_markers)
+                self.last_fit_loss = torch.where(never, prob['loss'], best_loss)
             else:
                 out, mfit = self.decode_vars(), (prob['markers_rec'].clone() if has_iter else None)
+                if has_iter:
+                    self.last_fit_loss = prob['loss'].clone()
             smplxparams_list.append(out)
             markers_fit_list.append(None if mfit is None else mfit.cpu().numpy())
         self.reset()
@@ -478,7 +483,9 @@ class FittingOP:
                 log_every=0):
         """fittingop.py:343-499 for a batch.  Returns ``(markers_fit_list, smplxparams_list, save_loss)``:
         three entries (one per stage) of [B,143,3] arrays / parameter dicts of [B,.] tensors; ``save_loss``
-        maps every key of the reference's ``save_loss`` to an array [n_iterations, B]."""
+        maps every key of the reference's ``save_loss`` to an array [n_iterations, B].  ``self.last_fit_loss`` [B] is the
+        loss of the state returned last (the best stage-3 iteration's where the rule of :429-447 picked one, else the last
+        iteration's): what a best-of-N selection over candidates compares."""
         self.bm = self.bm_male if gender == 'male' else self.bm_female
         if self.bm is None:
             raise ValueError('no body model was created for gender %r' % gender)
@@ -526,8 +533,11 @@ class FittingOP:
                 never = best_eval >= 10000.0
                 out = {k: torch.where(never[:, None], final[k], best_params[k]) for k in final}
                 mfit = torch.where(never[:, None, None], markers_fit.detach(), best_markers)
+                self.last_fit_loss = torch.where(never, loss.detach(), best_eval)
             else:
                 out, mfit = final, (markers_fit.detach() if markers_fit is not None else None)
+                if markers_fit is not None:
+                    self.last_fit_loss = loss.detach().clone()
             smplxparams_list.append(out)
             markers_fit_list.append(None if mfit is None else mfit.cpu().numpy())
         self.reset()

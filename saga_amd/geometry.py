@@ -51,8 +51,7 @@ def vertex_normals(model, verts):
         raise ValueError('verts has %d vertices, the model %d' % (V, model.num_verts))
     out = torch.empty_like(verts)
     lib = _lib.load()
-    _lib.check(lib.saga_vertex_normals(model.handle(verts.device), _lib.ptr(verts), _lib.ptr(out), B, _lib.stream()),
-               'saga_vertex_normals')
+    _lib.call('saga_vertex_normals', verts.device, model.handle(verts.device), _lib.ptr(verts), _lib.ptr(out), B)
     return out
 
 
@@ -65,6 +64,6 @@ def vertex_normals_subset(model, verts, sel):
         raise ValueError('verts has %d vertices, the model %d' % (V, model.num_verts))
     out = torch.empty(B, sel.shape[0], 3, device=verts.device, dtype=torch.float32)
     lib = _lib.load()
-    _lib.check(lib.saga_vertex_normals_subset(model.handle(verts.device), _lib.ptr(verts), _lib.ptr(sel), sel.shape[0],
-                                              _lib.ptr(out), B, _lib.stream()), 'saga_vertex_normals_subset')
+    _lib.call('saga_vertex_normals_subset', verts.device, model.handle(verts.device), _lib.ptr(verts), _lib.ptr(sel), sel.shape[0],
+                                              _lib.ptr(out), B)
     return out

@@ -69,10 +69,10 @@ class _GraspLossFn(torch.autograd.Function):
         idx_h2o = torch.empty(B, H, **i32)
         idx_o2h = torch.empty(B, O, **i32)
         P = _lib.ptr
-        _lib.check(lib.saga_grasp_loss_fwd(model.handle(dev), ctypes.byref(tables.struct), P(verts_c), P(obj), P(obj_normals),
+        _lib.call('saga_grasp_loss_fwd', dev, model.handle(dev), ctypes.byref(tables.struct), P(verts_c), P(obj), P(obj_normals),
                                            P(markers_target), P(c_markers), P(c_object), P(terms), P(markers_rec), P(hand_rec),
                                            P(hand_normals), P(h2o_marker), P(h2o_signed), P(o2h_signed), P(idx_m2o), P(idx_h2o),
-                                           P(idx_o2h), B, O, _lib.stream()), 'saga_grasp_loss_fwd')
+                                           P(idx_o2h), B, O)
         ctx.model, ctx.tables = model, tables
         ctx.save_for_backward(verts_c, obj, markers_target, c_markers, c_object, markers_rec, hand_rec, h2o_signed, o2h_signed,
                               idx_m2o, idx_h2o, idx_o2h)
@@ -90,10 +90,9 @@ class _GraspLossFn(torch.autograd.Function):
         g_terms = g_terms.contiguous()
         g_verts = torch.empty_like(verts)
         P = _lib.ptr
-        _lib.check(lib.saga_grasp_loss_bwd(ctx.model.handle(verts.device), ctypes.byref(ctx.tables.struct), P(g_terms), P(verts),
+        _lib.call('saga_grasp_loss_bwd', verts.device, ctx.model.handle(verts.device), ctypes.byref(ctx.tables.struct), P(g_terms), P(verts),
                                            P(obj), P(markers_target), P(c_markers), P(c_object), P(markers_rec), P(hand_rec),
-                                           P(h2o_signed), P(o2h_signed), P(idx_m2o), P(idx_h2o), P(idx_o2h), P(g_verts), B, O,
-                                           _lib.stream()), 'saga_grasp_loss_bwd')
+                                           P(h2o_signed), P(o2h_signed), P(idx_m2o), P(idx_h2o), P(idx_o2h), P(g_verts), B, O)
         return g_verts, None, None, None, None, None, None, None
 
 

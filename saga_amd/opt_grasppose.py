@@ -34,13 +34,16 @@ def fitting_results_dict(markers, markers_fit, smplxparams, gender, object_conta
     }
 
 
-def pose_opt(fittingop, samples_results, n_random_samples, obj, gender, save_dir=None, rank=0, world=1):
+def pose_opt(fittingop, samples_results, n_random_samples, obj, gender, save_dir=None, rank=0, world=1, gather=False):
     """``pose_opt`` of the reference for a batch: ``samples_results`` holds ``verts_object``/``normal_object``
     [n,O,3], ``global_orient_object``, ``transf_transl`` [n,.] and ``markers_gen`` [n*k,143,3],
     ``object_contact_gen`` [n*k,O], ``markers_contact_gen`` [n*k,143] (``:166-176``).  Candidate ``i*k + j`` is
     random sample j of object pose i.  With ``world > 1`` this rank fits its contiguous block of candidates
     (``saga_amd.distributed.shard_range``) and the returned dict holds that block only.
-    ``fittingop.batch_size`` must equal the number of candidates fitted here."""
+    ``fittingop.batch_size`` must equal the number of candidates fitted here.  ``gather=True`` (needs an initialised
+    ``torch.distributed`` group when ``world > 1``): the per-candidate loss and parameters of every rank are all-gathered
+    (``saga_amd.distributed.gather_candidates``, one fused buffer over RCCL), the returned dict holds ALL N candidates plus
+    ``'loss'`` [N] and ``'best_of_n'`` (index of the best random sample of every object pose); rank 0 writes the file."""
     from .distributed import shard_range
     dev = fittingop.device
     t = lambda k: torch.as_tensor(np.asarray(samples_results[k]), dtype=torch.float32)
@@ -61,6 +64,23 @@ def pose_opt(fittingop, samples_results, n_random_samples, obj, gender, save_dir
     sl = slice(lo, hi)
     d = lambda x: x[sl].to(dev)
     markers_fit, smplxparams, _loss = fittingop.fitting(d(markers), d(oc), d(mc), d(verts_o), d(normals_o), gender)
+    if gather:
+        from .distributed import best_of_n, gather_candidates
+        loss = fittingop.last_fit_loss
+        p = dict(smplxparams[-1])
+        # the fitted markers ride along in the fused buffer as one more 'parameter' block of body_pose-like rows
+        mf = torch.as_tensor(markers_fit[-1], dtype=torch.float32, device=dev).reshape(hi - lo, -1)
+        p['body_pose'] = torch.cat([p['body_pose'].reshape(hi - lo, -1), mf], dim=1)
+        gl, gp = gather_candidates(loss, p, n_total=N)
+        mf_all = gp['body_pose'][:, 63:].reshape(N, -1, 3)
+        gp['body_pose'] = gp['body_pose'][:, :63]
+        out = fitting_results_dict(markers, mf_all, gp, gender, oc, mc, obj, verts_o, go, tt)
+        if save_dir is not None and rank == 0:
+            os.makedirs(save_dir, exist_ok=True)
+            np.savez(os.path.join(save_dir, 'fitting_results.npz'), **out)
+        out['loss'] = gl.detach().cpu().numpy()
+        out['best_of_n'] = best_of_n(gl, gp, k)[0].cpu().numpy()
+        return out
     out = fitting_results_dict(markers[sl], markers_fit[-1], smplxparams[-1], gender, oc[sl], mc[sl], obj, verts_o[sl], go[sl], tt[sl])
     if save_dir is not None:
         os.makedirs(save_dir, exist_ok=True)

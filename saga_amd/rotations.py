@@ -18,8 +18,7 @@ class _Cont6dToAA(torch.autograd.Function):
         n = x.shape[0]
         aa = torch.empty(n, 3, device=x.device, dtype=torch.float32)
         jac = torch.empty(n, 18, device=x.device, dtype=torch.float32)
-        _lib.check(_lib.load().saga_cont6d_to_aa_fwd(_lib.ptr(x), _lib.ptr(aa), _lib.ptr(jac), n, _lib.stream()),
-                   'saga_cont6d_to_aa_fwd')
+        _lib.call('saga_cont6d_to_aa_fwd', x.device, _lib.ptr(x), _lib.ptr(aa), _lib.ptr(jac), n)
         ctx.save_for_backward(jac)
         ctx.in_shape = x6.shape
         return aa
@@ -30,8 +29,7 @@ class _Cont6dToAA(torch.autograd.Function):
         g = g_aa.contiguous()
         n = jac.shape[0]
         gx = torch.empty(n, 6, device=g.device, dtype=torch.float32)
-        _lib.check(_lib.load().saga_cont6d_to_aa_bwd(_lib.ptr(jac), _lib.ptr(g), _lib.ptr(gx), n, _lib.stream()),
-                   'saga_cont6d_to_aa_bwd')
+        _lib.call('saga_cont6d_to_aa_bwd', jac.device, _lib.ptr(jac), _lib.ptr(g), _lib.ptr(gx), n)
         return gx.reshape(ctx.in_shape)
 
 

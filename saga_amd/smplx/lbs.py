@@ -14,7 +14,7 @@ class _BatchRodrigues(torch.autograd.Function):
         rv = rot_vecs.contiguous()
         out = torch.empty(rv.shape[0], 3, 3, device=rv.device, dtype=torch.float32)
         lib = _lib.load()
-        _lib.check(lib.saga_rodrigues_fwd(_lib.ptr(rv), _lib.ptr(out), rv.shape[0], _lib.stream()), 'saga_rodrigues_fwd')
+        _lib.call('saga_rodrigues_fwd', rv.device, _lib.ptr(rv), _lib.ptr(out), rv.shape[0])
         ctx.save_for_backward(rv)
         return out
 
@@ -24,7 +24,7 @@ class _BatchRodrigues(torch.autograd.Function):
         g = g.contiguous()
         out = torch.empty_like(rv)
         lib = _lib.load()
-        _lib.check(lib.saga_rodrigues_bwd(_lib.ptr(rv), _lib.ptr(g), _lib.ptr(out), rv.shape[0], _lib.stream()), 'saga_rodrigues_bwd')
+        _lib.call('saga_rodrigues_bwd', rv.device, _lib.ptr(rv), _lib.ptr(g), _lib.ptr(out), rv.shape[0])
         return out
 
 
@@ -58,9 +58,9 @@ class _LBS(torch.autograd.Function):
         chain = torch.empty(B, 55, 12, **f32)
         A = torch.empty(B, 55, 12, **f32)
         v_posed = torch.empty(B, npad, **f32)
-        _lib.check(lib.saga_smplx_fwd(h, _lib.ptr(shape), _lib.ptr(full_pose), _lib.ptr(transl), _lib.ptr(vertices),
+        _lib.call('saga_smplx_fwd', dev, h, _lib.ptr(shape), _lib.ptr(full_pose), _lib.ptr(transl), _lib.ptr(vertices),
                                       _lib.ptr(joints), _lib.ptr(feat), _lib.ptr(rot), _lib.ptr(jrest), _lib.ptr(chain),
-                                      _lib.ptr(A), _lib.ptr(v_posed), B, _lib.stream()), 'saga_smplx_fwd')
+                                      _lib.ptr(A), _lib.ptr(v_posed), B)
         ctx.model = model
         ctx.has_transl = transl is not None
         ctx.save_for_backward(full_pose, rot, jrest, chain, A, v_posed)
@@ -88,10 +88,10 @@ class _LBS(torch.autograd.Function):
         ws_slab = torch.empty(_lib.BWD_SPLITK, B, _lib.FEAT_K, **f32) if has_v else None
         ws_dA = torch.empty(B, _lib.DA_STRIDE, **f32)
         ws_gv = torch.empty(B, model.num_verts, 3, **f32) if (g_joints is not None and model.joints_touch_verts) else None
-        _lib.check(lib.saga_smplx_bwd(model.handle(dev), _lib.ptr(g_vertices), _lib.ptr(g_joints), _lib.ptr(full_pose),
+        _lib.call('saga_smplx_bwd', dev, model.handle(dev), _lib.ptr(g_vertices), _lib.ptr(g_joints), _lib.ptr(full_pose),
                                       _lib.ptr(rot), _lib.ptr(jrest), _lib.ptr(chain), _lib.ptr(A), _lib.ptr(v_posed),
                                       _lib.ptr(g_shape), _lib.ptr(g_pose), _lib.ptr(g_transl), _lib.ptr(ws_gvp),
-                                      _lib.ptr(ws_slab), _lib.ptr(ws_dA), _lib.ptr(ws_gv), B, _lib.stream()), 'saga_smplx_bwd')
+                                      _lib.ptr(ws_slab), _lib.ptr(ws_dA), _lib.ptr(ws_gv), B)
         return None, g_shape, g_pose, (g_transl if ctx.has_transl else None)
 
 
@@ -122,9 +122,9 @@ class _LBSSelected(torch.autograd.Function):
         chain = torch.empty(B, 55, 12, **f32)
         A = torch.empty(B, 55, 12, **f32)
         v_posed = torch.empty(B, npad, **f32)
-        _lib.check(lib.saga_smplx_fwd(h, _lib.ptr(shape), _lib.ptr(full_pose), _lib.ptr(transl), _lib.ptr(vertices),
+        _lib.call('saga_smplx_fwd', dev, h, _lib.ptr(shape), _lib.ptr(full_pose), _lib.ptr(transl), _lib.ptr(vertices),
                                       _lib.ptr(joints), _lib.ptr(feat), _lib.ptr(rot), _lib.ptr(jrest), _lib.ptr(chain),
-                                      _lib.ptr(A), _lib.ptr(v_posed), B, _lib.stream()), 'saga_smplx_fwd')
+                                      _lib.ptr(A), _lib.ptr(v_posed), B)
         U = sel.shape[0]
         npad_s = lib.saga_model_npad(hs)
         v_posed_s = torch.zeros(B, npad_s, **f32)                      # the subset model's layout: [B, Npad_s], pad = 0
@@ -154,10 +154,9 @@ class _LBSSelected(torch.autograd.Function):
         ws_gvp = torch.empty(B, v_posed_s.shape[1], **f32)
         ws_slab = torch.empty(_lib.BWD_SPLITK, B, _lib.FEAT_K, **f32)
         ws_dA = torch.empty(B, _lib.DA_STRIDE, **f32)
-        _lib.check(lib.saga_smplx_bwd(ctx.subset, _lib.ptr(g_sel), None, _lib.ptr(full_pose), _lib.ptr(rot), _lib.ptr(jrest),
+        _lib.call('saga_smplx_bwd', dev, ctx.subset, _lib.ptr(g_sel), None, _lib.ptr(full_pose), _lib.ptr(rot), _lib.ptr(jrest),
                                       _lib.ptr(chain), _lib.ptr(A), _lib.ptr(v_posed_s), _lib.ptr(g_shape), _lib.ptr(g_pose),
-                                      _lib.ptr(g_transl), _lib.ptr(ws_gvp), _lib.ptr(ws_slab), _lib.ptr(ws_dA), None, B,
-                                      _lib.stream()), 'saga_smplx_bwd')
+                                      _lib.ptr(g_transl), _lib.ptr(ws_gvp), _lib.ptr(ws_slab), _lib.ptr(ws_dA), None, B)
         return None, None, None, g_shape, g_pose, (g_transl if ctx.has_transl else None)
 
 

@@ -36,6 +36,16 @@ def _worker(rank, world, port, n_total, q):
         s, e = sd.shard_range(n_total, rank, world)
         gl, gp = sd.gather_candidates(losses[s:e], {k: v[s:e] for k, v in params.items()}, n_total=n_total)
         ok = torch.equal(gl, losses) and all(torch.equal(gp[k], params[k]) for k in params)
+        # without n_total the per-rank counts are exchanged: ragged shards (here 1 row against the rest) still line up
+        s2, e2 = (0, 1) if rank == 0 else (1, n_total)
+        gl2, gp2 = sd.gather_candidates(losses[s2:e2], {k: v[s2:e2] for k, v in params.items()})
+        ok = ok and torch.equal(gl2, losses) and all(torch.equal(gp2[k], params[k]) for k in params)
+        # a shard that is not this rank's block of n_total is refused on every rank (no hang: the counts were gathered first)
+        try:
+            sd.gather_candidates(losses[s2:e2], {k: v[s2:e2] for k, v in params.items()}, n_total=n_total + (0 if n_total > 2 else 1))
+            ok = ok and (e2 - s2) == (e - s)
+        except ValueError:
+            pass
         idx, bl, bp = sd.best_of_n(gl, gp, group_size=n_total // 2) if n_total % 2 == 0 else (None, None, None)
         q.put((rank, bool(ok), None if idx is None else idx.tolist()))
     finally:

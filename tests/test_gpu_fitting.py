@@ -213,6 +213,68 @@ def test_workspace_reuse_across_problems_is_clean(body_model_dir):
                        op_b.workspace_view('g_vertices', 2048, (B, op_b.bm.num_verts, 3)))
 
 
+def test_workspace_relayout_between_object_sizes_is_clean(body_model_dir):
+    """The workspace layout depends on O (the object-sized buffers sit before the dense vertex gradient), and FittingOP keeps
+    one buffer.  O = 2048, then 1024, then 2048 again on one op: the smaller layout writes gradients into what is g_vertices
+    under the larger one, so the 'rows already zero' marks of the larger layout must not survive (they did).  Also a
+    saga_fit_decode in between (it uses the head of the same buffer).  Every step equals a fresh op's, bit for bit."""
+    B = 3
+    op, vp, idx, var_np, _ = _setup(body_model_dir, B)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def data(O):
+        vo, no, _, _ = make_object_cloud(B, n_points=O, seed=3)
+        mk, mc, oc = make_grasp_targets(B, vo, seed=4815)
+        return cu(mk), cu(vo), cu(no), cu(oc), cu(mc)
+
+    def run(o, O, steps=2):
+        o.bm = o.bm_male
+        o.reset()
+        o.set_variables(var_np)
+        prob = o.make_problem(*data(O))
+        for _ in range(steps):
+            loss, mk = o.native_step(2, prob)
+        return loss.clone(), mk.clone(), o.vars.clone(), o.workspace_view('g_vertices', O, (B, o.bm.num_verts, 3)).clone()
+
+    seq = [2048, 1024, 2048, 512, 2048]
+    got = []
+    for i, O in enumerate(seq):
+        got.append(run(op, O))
+        if i == 2:
+            op.decode_vars()
+    for O, g in zip(seq, got):
+        fresh, *_ = _setup(body_model_dir, B)
+        want = run(fresh, O)
+        for a, b, name in zip(g, want, ('loss', 'markers', 'vars', 'g_vertices')):
+            assert torch.equal(a, b), (O, name)
+
+
+def test_ops_follow_the_tensors_device_not_the_current_device(body_model_dir):
+    """every op launches on the device (and torch stream of the device) its tensors live on; mixed devices are
+    rejected.  With one visible GPU the cross-device half is skipped."""
+    from saga_amd import _lib
+    from saga_amd.chamfer_distance import ChamferDistance
+    x = torch.randn(2, 50, 3, device='cuda:0')
+    with pytest.raises(RuntimeError, match='one device|GPU only'):
+        _lib.require_device(x, torch.randn(2, 50, 3))
+    if torch.cuda.device_count() < 2:
+        return
+    y1 = torch.randn(2, 70, 3, device='cuda:1')
+    with pytest.raises(RuntimeError, match='one device'):
+        ChamferDistance(x, y1)
+    x1 = x.to('cuda:1')
+    assert torch.cuda.current_device() == 0
+    d1, d2, i1, i2 = ChamferDistance(x1, y1)               # current device 0, tensors on 1
+    d1r, d2r, i1r, i2r = ChamferDistance(x, y1.to('cuda:0'))
+    assert d1.device.index == 1 and torch.equal(i1.cpu(), i1r.cpu()) and torch.equal(d2.cpu(), d2r.cpu())
+    op, vp, idx, var_np, d = _setup(body_model_dir, 2)
+    h0 = op.bm_male.handle(torch.device('cuda:0'))
+    with torch.cuda.device(1):                                # a device-0 model handle with device 1 current: refused
+        v = torch.zeros(2, op.bm_male.num_verts, 3, device='cuda:1')
+        rc = _lib.load().saga_vertex_normals(h0, _lib.ptr(v), _lib.ptr(v), 2, None)
+    assert rc == -1 and b'current device' in _lib.load().saga_last_error()
+
+
 def test_loss_vertices_only_variant_equals_full_mesh(body_model_dir):
     """`loss_vertices_only=True` builds the body model for the ~1,100 vertices the loss reads (saga_model_create_subset).
     The kept vertices are bit-identical to the full mesh's, so the first iteration's loss terms, counts and fitted markers

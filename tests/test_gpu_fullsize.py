@@ -26,7 +26,8 @@ def _inputs(B):
     return make_candidate_params(B, seed=1234, scale=0.3), dict(mk=mk, mc=mc, oc=oc, vo=vo, no=no)
 
 
-def test_candidates_are_independent_at_full_batch(body_model_dir):
+@pytest.mark.parametrize('B_FULL', [4096, 1024])          # the metric's batch, and BASELINE config 2
+def test_candidates_are_independent_at_full_batch(body_model_dir, B_FULL):
     var, d = _inputs(B_FULL)
     cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     big = _op(body_model_dir, B_FULL)
@@ -35,7 +36,8 @@ def test_candidates_are_independent_at_full_batch(body_model_dir):
     terms = torch.zeros(B_FULL, 16, device='cuda')
     for _ in range(2):
         loss_big, mk_big = big.native_step(2, prob, terms)
-    sel = np.array([0, 3, 130, 1001, 2047, 2048, 4000, 4095])
+    sel = np.array([0, 3, 130, 1001, 2047, 2048, 4000, 4095]) % B_FULL
+    sel = np.unique(sel)
     small = _op(body_model_dir, len(sel))
     small.set_variables({k: v[sel] for k, v in var.items()})
     ps = small.make_problem(*(cu(d[k][sel]) for k in ('mk', 'vo', 'no', 'oc', 'mc')))
@@ -105,3 +107,12 @@ def test_pose_opt_writes_reference_schema(body_model_dir, tmp_path):
     assert back['body'][()]['body_pose'].shape == (n * k, 63)
     assert np.array_equal(back['object'][()]['verts_object'][k], vo[1])          # candidate k belongs to object pose 1
     assert np.array_equal(out['markers'], mk)
+    # gather=True (one rank: no process group needed): same rows + the per-candidate loss and the best random sample per object pose
+    op2 = FittingOP({'batch_size': n * k, 'device': 'cuda', 'body_model_path': body_model_dir, 'vposer': VPoserDecoder(seed=0),
+                     'genders': ('male',), 'num_iter': [2, 2, 2], 'verbose': False})
+    out2 = pose_opt(op2, samples, k, 'camera', 'male', gather=True)
+    for key in out['body']:
+        assert np.array_equal(out2['body'][key], out['body'][key]), key
+    assert np.array_equal(out2['markers_fit'], out['markers_fit'])
+    assert out2['loss'].shape == (n * k,) and np.isfinite(out2['loss']).all()
+    assert out2['best_of_n'].tolist() == [int(out2['loss'][:k].argmin()), k + int(out2['loss'][k:].argmin())]
