@@ -8,6 +8,7 @@ for streaming stores.  Separate --pmc passes (one per counter group)."""
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
@@ -53,6 +54,8 @@ for k in sorted(cnt):
         d['hbm_read_bytes'] = 2.0 * c['FETCH_SIZE'] * 1024.0       # gfx950: 128-B requests tallied at 64 B
         d['hbm_write_bytes'] = c['WRITE_SIZE'] * 1024.0
         d['hbm_bytes'] = d['hbm_read_bytes'] + d['hbm_write_bytes']
+    if c.get('SQ_LDS_IDX_ACTIVE'):
+        d['lds_conflict_ratio'] = c.get('SQ_LDS_BANK_CONFLICT', 0.0) / c['SQ_LDS_IDX_ACTIVE']   # conflict cycles per active LDS cycle
     if c.get('GRBM_GUI_ACTIVE'):
         cyc = c['GRBM_GUI_ACTIVE'] / 8.0                            # summed over the 8 XCDs
         d['gpu_cycles'] = cyc
@@ -63,9 +66,25 @@ for k in sorted(cnt):
     lines.append(k)
     for n, v in sorted(c.items()):
         lines.append('    %-32s %18.1f' % (n, v))
-    for n in ('hbm_bytes', 'mfma_util', 'valu_issue_util'):
+    for n in ('hbm_bytes', 'mfma_util', 'valu_issue_util', 'lds_conflict_ratio'):
         if n in d:
             lines.append('    -> %-29s %18.4g' % (n, d[n]))
+# what the numbers describe: the kernel sources (sha256[:16] per file), the workload of the profiled command and the GEMM
+# environment switches -- bench.py emits `roofline.traffic` only when these match the run it reports (git_head is added when the
+# summary is copied into profiles/ in the build container: the GPU box has no .git)
+csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'saga_amd', 'csrc')
+meta = {'src_sha16': {os.path.basename(p): hashlib.sha256(open(p, 'rb').read()).hexdigest()[:16]
+                      for p in sorted(glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.h')))},
+        'env': {k: os.environ.get(k, '') for k in ('SAGA_GEMM_LEPI', 'SAGA_GEMM_XCD')},
+        'kernels': sorted(k for k in out if k.startswith(OURS))}
+try:
+    line = [l for l in open(os.path.join(root, 'bench_trace.json')) if l.startswith('{')][-1]
+    cfg = json.loads(line)['config']
+    meta.update(B=cfg['candidates_per_gpu'], n_obj=cfg['object_points'], V=10475 if 'V=10475' in cfg['workload'] else None,
+                command='bench.py --steps 10 --warmup 3 --no-cpu-baseline (kernel trace); --steps 3 --warmup 1 (PMC passes)')
+except (OSError, IndexError, KeyError, ValueError):
+    pass
+out['_meta'] = meta
 open(os.path.join(root, 'summary.txt'), 'w').write('\n'.join(lines) + '\n')
 json.dump(out, open(os.path.join(root, 'summary.json'), 'w'), indent=1, sort_keys=True)
 print('\n'.join(lines))
