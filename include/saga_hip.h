@@ -120,6 +120,20 @@ int saga_smplx_bwd(const saga_model_t* m, const float* g_vertices, const float* 
                    float* ws_gvp, float* ws_slab, float* ws_dA, float* ws_gv,
                    int B, void* stream);
 
+/* saga_smplx_bwd for callers that cannot allocate.  NO counterpart in the reference: it exists for callers under HIP graph
+ * capture, tight serving loops and harnesses that forbid hipMalloc -- they still pass inputs and outputs, but the four
+ * workspaces (ws_gvp, ws_slab, ws_dA, ws_gv) live in a static device array inside the library (18.4 MB per GPU the library runs
+ * on, held until the process ends).  Same arguments otherwise, same results bit for bit.  Limits: B <= SAGA_NOALLOC_MAX_B
+ * and saga_model_npad(m) <= SAGA_NOALLOC_MAX_NPAD (SMPL-X's 10,475 vertices fit), else SAGA_EINVAL.  It calls no hipMalloc /
+ * hipFree / allocating routine (per-kernel profiling is suspended inside it).  Every call on a GPU shares that GPU's array:
+ * calls that overlap on one GPU (two streams, two threads) race -- serialise them. */
+#define SAGA_NOALLOC_MAX_B     64
+#define SAGA_NOALLOC_MAX_NPAD  31488
+int saga_smplx_bwd_noalloc(const saga_model_t* m, const float* g_vertices, const float* g_joints,
+                           const float* full_pose, const float* rot, const float* jrest, const float* chain,
+                           const float* A, const float* v_posed,
+                           float* g_shape, float* g_full_pose, float* g_transl, int B, void* stream);
+
 /* smplx.lbs.batch_rodrigues(rot_vecs[N,3]) -> [N,3,3]
  * (imported directly at WholeGraspPose/models/objectmodel.py:6,38 and opt_grasppose.py:10,38). */
 int saga_rodrigues_fwd(const float* rot_vecs, float* rot_mats, int N, void* stream);

@@ -20,6 +20,8 @@ FEAT_K = 512
 N_ALIGN = 128
 BWD_SPLITK = 16
 DA_STRIDE = 840
+NOALLOC_MAX_B = 64
+NOALLOC_MAX_NPAD = 31488
 
 
 class ModelDesc(ctypes.Structure):
@@ -88,6 +90,7 @@ PROTOTYPES = {
     'saga_model_weight_nnz': (ctypes.c_int, [ctypes.c_void_p]),
     'saga_smplx_fwd': (ctypes.c_int, [ctypes.c_void_p] + [c_float_p] * 11 + [ctypes.c_int, c_stream]),
     'saga_smplx_bwd': (ctypes.c_int, [ctypes.c_void_p] + [c_float_p] * 15 + [ctypes.c_int, c_stream]),
+    'saga_smplx_bwd_noalloc': (ctypes.c_int, [ctypes.c_void_p] + [c_float_p] * 11 + [ctypes.c_int, c_stream]),
     'saga_rodrigues_fwd': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, c_stream]),
     'saga_rodrigues_bwd': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, ctypes.c_int, c_stream]),
     'saga_cont6d_to_aa_fwd': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, ctypes.c_int, c_stream]),

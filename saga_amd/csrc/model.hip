@@ -27,6 +27,8 @@ int saga_check_device(int device, const char* what) {
 }
 extern "C" int saga_version(void) { return 100; }
 
+int saga_noalloc_init_device(int device);
+
 template <typename T>
 static int upload(T** dst, const std::vector<T>& src) {
     size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
@@ -258,6 +260,7 @@ static int model_create_impl(saga_model_t** out, const saga_model_desc_t* d, con
             (rc = upload(&m->lmk_verts, lv)) || (rc = upload(&m->lmk_bary, lb)) || (rc = upload(&m->extra_verts, ev)))
             goto fail;
     }
+    if ((rc = saga_noalloc_init_device(dev))) goto fail;       // this device's copy of the static scratch (smplx_api.hip)
     *out = m;
     return 0;
 fail:

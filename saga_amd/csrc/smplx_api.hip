@@ -26,13 +26,14 @@ int saga_launch_skin_bwd(const saga_model* m, const float* A, const float* g_ver
 #include <vector>
 struct ProfPair { hipEvent_t a, b; int id; };
 static int g_prof_on = 0;       // 0 off, 1 every kernel, 2 only the blend GEMM launches (the roofline kernel)
+static int g_prof_suspend = 0;  // set for the duration of saga_smplx_bwd_noalloc: event creation allocates
 static std::vector<ProfPair> g_prof_pairs;
 static std::vector<ProfPair> g_prof_pool;
 
 struct ProfScope {
     hipStream_t st; hipEvent_t b = nullptr; bool on;
     ProfScope(int id, hipStream_t s)
-        : st(s), on(g_prof_on == 1 || (g_prof_on == 2 && (id == SAGA_PROF_BLEND_FWD || id == SAGA_PROF_BLEND_BWD))) {
+        : st(s), on(!g_prof_suspend && (g_prof_on == 1 || (g_prof_on == 2 && (id == SAGA_PROF_BLEND_FWD || id == SAGA_PROF_BLEND_BWD)))) {
         if (!on) return;
         ProfPair p;
         if (!g_prof_pool.empty()) { p = g_prof_pool.back(); g_prof_pool.pop_back(); }
@@ -149,4 +150,63 @@ extern "C" int saga_smplx_bwd(const saga_model_t* m, const float* g_vertices, co
     PROF(SAGA_PROF_POSE_BWD);
     return saga_launch_pose_bwd(m, ws_dA, g_pj, g_jsum, ws_slab, saga_blend_bwd_splitk(m), rot, jrest, chain, full_pose, g_shape, g_full_pose,
                                 g_transl, B, has_verts, st);
+}
+
+// ---- the entry point that allocates nothing -----------------------------------------------------------------------
+// saga_smplx_bwd with its four workspaces in a file-scope device array instead of caller-allocated buffers, for callers
+// that cannot call hipMalloc (under HIP graph capture, tight serving loops, harnesses that forbid it).  Each GPU the library
+// runs on holds its own copy of the array (18.4 MB) until the process ends.  In host code the array's NAME is a host-side
+// stand-in, not a device address: its memory is reached only through the pointer hipGetSymbolAddress returns, looked up once
+// per device with that device current (at saga_model_create -- saga_noalloc_init_device -- or on the first call) and kept per device.
+#define NOALLOC_MAX_B    SAGA_NOALLOC_MAX_B
+#define NOALLOC_MAX_NPAD SAGA_NOALLOC_MAX_NPAD
+#define NOALLOC_MAX_DEVICES 64
+static constexpr size_t SCR_GVP  = (size_t)NOALLOC_MAX_B * NOALLOC_MAX_NPAD;             // ws_gvp  [B, Npad]
+static constexpr size_t SCR_SLAB = (size_t)SAGA_BWD_SPLITK * NOALLOC_MAX_B * FEAT_K;     // ws_slab [16, B, 512]
+static constexpr size_t SCR_DA   = ((size_t)NOALLOC_MAX_B * SAGA_DA_STRIDE + 63) / 64 * 64;   // ws_dA [B, 840]
+static constexpr size_t SCR_GV   = (size_t)NOALLOC_MAX_B * NOALLOC_MAX_NPAD;             // ws_gv   [B, V, 3]  (3V <= Npad)
+static constexpr size_t SCR_TOTAL = SCR_GVP + SCR_SLAB + SCR_DA + SCR_GV;
+static __device__ __align__(256) float scratch[SCR_TOTAL];
+static float* g_scratch_ptr[NOALLOC_MAX_DEVICES];      // per device: the address of ITS copy of `scratch`
+
+// looks up (once) the current device's copy of the scratch array; *out = its device address
+static int noalloc_scratch(int device, float** out) {
+    SAGA_CHECK_ARG(device >= 0 && device < NOALLOC_MAX_DEVICES, "saga_smplx_bwd_noalloc: device %d beyond %d", device, NOALLOC_MAX_DEVICES);
+    if (!g_scratch_ptr[device]) {
+        float* p = nullptr;
+        SAGA_HIP(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));       // of the CURRENT device (checked by the callers)
+        SAGA_CHECK_ARG(p, "saga_smplx_bwd_noalloc: hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return 0;
+}
+
+// called by saga_model_create with the model's device current: the lookup happens at set-up, not inside a capture
+int saga_noalloc_init_device(int device) {
+    float* p;
+    return noalloc_scratch(device, &p);
+}
+
+extern "C" int saga_smplx_bwd_noalloc(const saga_model_t* m, const float* g_vertices, const float* g_joints, const float* full_pose,
+                                      const float* rot, const float* jrest, const float* chain, const float* A,
+                                      const float* v_posed, float* g_shape, float* g_full_pose, float* g_transl, int B,
+                                      void* stream) {
+    SAGA_CHECK_ARG(m, "saga_smplx_bwd_noalloc: null model");
+    SAGA_CHECK_DEVICE(m, "saga_smplx_bwd_noalloc");
+    SAGA_CHECK_ARG(B >= 0 && B <= NOALLOC_MAX_B, "saga_smplx_bwd_noalloc: batch %d exceeds the static scratch (at most %d candidates "
+                   "per call; use saga_smplx_bwd with caller workspaces beyond that)", B, NOALLOC_MAX_B);
+    SAGA_CHECK_ARG(m->Npad <= NOALLOC_MAX_NPAD, "saga_smplx_bwd_noalloc: the model's padded row (%d floats) exceeds the static scratch (%d)",
+                   m->Npad, NOALLOC_MAX_NPAD);
+    if (B == 0) return 0;
+    float* base = nullptr;
+    int rc = noalloc_scratch(m->device, &base);
+    if (rc) return rc;
+    // nothing in the scratch has to start at zero: saga_smplx_bwd treats its workspaces as undefined on entry (ws_gv is
+    // copied / cleared inside when g_joints is given)
+    g_prof_suspend = 1;
+    rc = saga_smplx_bwd(m, g_vertices, g_joints, full_pose, rot, jrest, chain, A, v_posed, g_shape, g_full_pose, g_transl,
+                        base, base + SCR_GVP, base + SCR_GVP + SCR_SLAB, base + SCR_GVP + SCR_SLAB + SCR_DA, B, stream);
+    g_prof_suspend = 0;
+    return rc;
 }
