@@ -156,8 +156,9 @@ int saga_cont6d_to_aa_bwd(const float* jac, const float* g_aa, float* g_x6, int 
  * ------------------------------------------------------------------------------------------ */
 int saga_chamfer_fwd(const float* x, const float* y, float* dist1, float* dist2,
                      int32_t* idx1, int32_t* idx2, int N, int P1, int P2, void* stream);
-/* the extension's own backward (NmDistanceGrad): g_x, g_y must be zero-initialised by the caller;
- * never driven by SAGA itself but part of the package's API. */
+/* the extension's own backward (NmDistanceGrad): the gradients are ADDED to g_x, g_y (zero-initialise them for the plain
+ * gradient); never driven by SAGA itself but part of the package's API.  Deterministic: a gather in
+ * a fixed order per point instead of the extension's float atomics -- bit-reproducible, batch-independent. */
 int saga_chamfer_bwd(const float* x, const float* y, const int32_t* idx1, const int32_t* idx2,
                      const float* g_dist1, const float* g_dist2, float* g_x, float* g_y,
                      int N, int P1, int P2, void* stream);

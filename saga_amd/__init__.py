@@ -4,7 +4,7 @@ Sub-packages mirror the operator packages the reference imports:
   saga_amd.smplx             ~ smplx             (create / SMPLX / lbs.batch_rodrigues)
   saga_amd.chamfer_distance  ~ chamfer_distance  (ChamferDistance)
   saga_amd.geometry          ~ utils/train_helper.point2point_signed + Open3D vertex normals
-  saga_amd.rotations         ~ utils/utils.RotConverter (cont2rotmat / rotmat2aa)
+  saga_amd.rotations         ~ utils/utils.RotConverter: rotmat2aa(cont2rotmat(x)) as one HIP op, cont6d_to_aa(x)
   saga_amd.vposer            ~ human_body_prior VPoser v1 decoder
   saga_amd.fitting           ~ WholeGraspPose/models/fittingop.FittingOP (batched)
 All arithmetic of the hot path runs in saga_amd/lib/libsaga_hip.so (HIP, gfx950); there is no CPU fallback.

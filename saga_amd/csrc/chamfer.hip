@@ -152,25 +152,62 @@ extern "C" int saga_chamfer_fwd(const float* x, const float* y, float* dist1, fl
     return rc;
 }
 
-// Backward of the two squared-distance outputs (the extension's NmDistanceGrad): for every point p of a with
-// neighbour k in b: g = 2 * g_dist[p] * (a_p - b_k); g_a[p] += g; g_b[k] -= g.  Many p share one k -> atomics.
-__global__ void nn_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, const int32_t* __restrict__ idx,
-                               const float* __restrict__ g_dist, float* __restrict__ g_a, float* __restrict__ g_b, int N,
-                               int Pa, int Pb) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)N * Pa) return;
-    const int n = (int)(i / Pa);
-    const int k = idx[i];
-    const float g = 2.0f * g_dist[i];
-    const float* ap = a + i * 3;
-    const float* bp = b + ((size_t)n * Pb + k) * 3;
-    float* ga = g_a + i * 3;
-    float* gb = g_b + ((size_t)n * Pb + k) * 3;
+// Backward of the two squared-distance outputs (the extension's NmDistanceGrad): for every point p of a with neighbour
+// k in b: g = 2 * g_dist[p] * (a_p - b_k); g_a[p] += g; g_b[k] -= g -- and the same with the roles swapped.  The CUDA
+// extension scatters with float atomicAdd (many p share one k), whose result depends on the order the atomics land in.
+// Here it is a GATHER: one lane owns one point p of a cloud and adds, in a fixed order, its own term and then the terms of
+// the other cloud's points q whose neighbour is p, in ascending q (the other cloud's neighbour indices stream through LDS,
+// four per broadcast read; a match is rare, so the loop is one compare per pair).  No atomics: bit-reproducible, and a
+// batch element's gradient does not depend on the batch around it.
+#define NG_THREADS 256
+#define NG_TILE 4096
+__global__ __launch_bounds__(NG_THREADS) void nn_grad_gather_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                    const int32_t* __restrict__ idx_ab, const float* __restrict__ g_dist_a,
+                                                                    const int32_t* __restrict__ idx_ba, const float* __restrict__ g_dist_b,
+                                                                    float* __restrict__ g_a, int Pa, int Pb) {
+    __shared__ __attribute__((aligned(16))) int32_t sidx[NG_TILE];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int p = blockIdx.x * NG_THREADS + tid;
+    const bool live = p < Pa;
+    const float* an = a + (size_t)n * Pa * 3;
+    const float* bn = b + (size_t)n * Pb * 3;
+    float ax = 0.f, ay = 0.f, az = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+    if (live) {
+        ax = an[p * 3]; ay = an[p * 3 + 1]; az = an[p * 3 + 2];
+        if (g_dist_a) {
+            const int k = idx_ab[(size_t)n * Pa + p];
+            const float g = 2.0f * g_dist_a[(size_t)n * Pa + p];
+            sx = g * (ax - bn[k * 3]); sy = g * (ay - bn[k * 3 + 1]); sz = g * (az - bn[k * 3 + 2]);
+        }
+    }
+    if (g_dist_b) {
+        const int32_t* ib = idx_ba + (size_t)n * Pb;
+        const float* gb = g_dist_b + (size_t)n * Pb;
+        const int me = live ? p : -2;
+        for (int t0 = 0; t0 < Pb; t0 += NG_TILE) {
+            const int cnt = min(NG_TILE, Pb - t0);
+            if (t0) __syncthreads();
+            for (int i = tid; i < NG_TILE; i += NG_THREADS) sidx[i] = i < cnt ? ib[t0 + i] : -1;
+            __syncthreads();
+            const int cnt4 = (cnt + 3) & ~3;
+            for (int j = 0; j < cnt4; j += 4) {
+                const int4 v = *reinterpret_cast<const int4*>(sidx + j);
+                if (v.x == me || v.y == me || v.z == me || v.w == me) {
+                    const int vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float v = g * (ap[c] - bp[c]);
-        atomicAdd(ga + c, v);
-        atomicAdd(gb + c, -v);
+                    for (int c = 0; c < 4; ++c)
+                        if (vv[c] == me) {
+                            const int q = t0 + j + c;
+                            const float g = 2.0f * gb[q];
+                            sx -= g * (bn[q * 3] - ax); sy -= g * (bn[q * 3 + 1] - ay); sz -= g * (bn[q * 3 + 2] - az);
+                        }
+                }
+            }
+        }
+    }
+    if (live) {
+        float* o = g_a + ((size_t)n * Pa + p) * 3;
+        o[0] += sx; o[1] += sy; o[2] += sz;
     }
 }
 
@@ -179,18 +216,14 @@ extern "C" int saga_chamfer_bwd(const float* x, const float* y, const int32_t* i
     SAGA_CHECK_ARG(N >= 0 && P1 >= 0 && P2 >= 0, "saga_chamfer_bwd: negative size");
     if (N == 0 || P1 == 0 || P2 == 0) return 0;
     SAGA_CHECK_ARG(x && y && g_x && g_y, "saga_chamfer_bwd: null argument");
+    SAGA_CHECK_ARG(N <= 65535, "saga_chamfer_bwd: batch %d exceeds 65535", N);
+    SAGA_CHECK_ARG(!g_dist1 || idx1, "saga_chamfer_bwd: idx1 missing");
+    SAGA_CHECK_ARG(!g_dist2 || idx2, "saga_chamfer_bwd: idx2 missing");
+    if (!g_dist1 && !g_dist2) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (g_dist1) {
-        SAGA_CHECK_ARG(idx1, "saga_chamfer_bwd: idx1 missing");
-        const size_t tot = (size_t)N * P1;
-        nn_grad_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(x, y, idx1, g_dist1, g_x, g_y, N, P1, P2);
-        SAGA_LAUNCH_CHECK();
-    }
-    if (g_dist2) {
-        SAGA_CHECK_ARG(idx2, "saga_chamfer_bwd: idx2 missing");
-        const size_t tot = (size_t)N * P2;
-        nn_grad_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(y, x, idx2, g_dist2, g_y, g_x, N, P2, P1);
-        SAGA_LAUNCH_CHECK();
-    }
+    nn_grad_gather_kernel<<<dim3((P1 + NG_THREADS - 1) / NG_THREADS, N), NG_THREADS, 0, st>>>(x, y, idx1, g_dist1, idx2, g_dist2, g_x, P1, P2);
+    SAGA_LAUNCH_CHECK();
+    nn_grad_gather_kernel<<<dim3((P2 + NG_THREADS - 1) / NG_THREADS, N), NG_THREADS, 0, st>>>(y, x, idx2, g_dist2, idx1, g_dist1, g_y, P2, P1);
+    SAGA_LAUNCH_CHECK();
     return 0;
 }

@@ -21,7 +21,7 @@ from . import _lib
 from . import smplx as _smplx
 from .geometry import point2point_signed, vertex_normals_subset
 from .grasp_loss import GraspTables, grasp_loss_terms
-from .rotations import RotConverter, cont6d_to_aa
+from .rotations import cont6d_to_aa
 from .vposer import VPoserDecoder
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'grasp_indices.npz')

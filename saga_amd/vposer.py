@@ -1,13 +1,14 @@
 """VPoser v1.0 decoder as used at ``WholeGraspPose/models/fittingop.py:65,142``
 (``human_body_prior``: ``vposer.decode(z, output_type='aa')``): 32 -> 512 -> 512 -> 126 MLP with
-leaky-relu(0.2), 21 x 6D -> rotation matrix -> axis-angle.  Stays on PyTorch/rocBLAS (SURVEY.md
-section 8f, f3); the pretrained snapshot is not available, so weights are random-initialised
-unless a state dict with the ``bodyprior_dec_*`` keys is loaded."""
+leaky-relu(0.2), 21 x 6D -> rotation matrix -> axis-angle.  This module is the autograd-path form (three
+``nn.Linear`` + the fused ``saga_cont6d_to_aa`` kernel) and the holder of the weights; ``saga_fit_step`` runs the same
+decoder inside the library.  The pretrained snapshot is not available, so weights are random-initialised unless a
+state dict with the ``bodyprior_dec_*`` keys is loaded."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .rotations import RotConverter, cont6d_to_aa
+from .rotations import cont6d_to_aa
 
 
 class VPoserDecoder(nn.Module):
@@ -30,12 +31,14 @@ class VPoserDecoder(nn.Module):
         x = F.leaky_relu(self.bodyprior_dec_fc1(Zin), negative_slope=0.2)
         x = F.leaky_relu(self.bodyprior_dec_fc2(x), negative_slope=0.2)   # dropout is inactive in eval mode
         x = self.bodyprior_dec_out(x)
+        # fused 6D -> axis-angle kernel (one launch instead of ~90); GPU only, like every op of the package
+        aa = cont6d_to_aa(x.reshape(-1, 6))
         if output_type == 'aa':
-            if x.is_cuda:      # fused 6D -> axis-angle kernel (one launch instead of ~90)
-                return cont6d_to_aa(x.reshape(-1, 6)).reshape(Zin.shape[0], 1, self.num_joints, 3)
-            return RotConverter.rotmat2aa(RotConverter.cont2rotmat(x.reshape(-1, 6))).reshape(
-                Zin.shape[0], 1, self.num_joints, 3)
-        return RotConverter.cont2rotmat(x.reshape(-1, 6)).reshape(Zin.shape[0], 1, self.num_joints, 9)
+            return aa.reshape(Zin.shape[0], 1, self.num_joints, 3)
+        # 'matrot' is not on the GraspPose-Opt path (fittingop.py:142 asks for 'aa'): R(aa) on the Rodrigues kernel, equal to
+        # the Gram-Schmidt matrix to rounding
+        from .smplx.lbs import batch_rodrigues
+        return batch_rodrigues(aa).reshape(Zin.shape[0], 1, self.num_joints, 9)
 
     def weights_dict(self, dtype=torch.float64):
         """Plain tensors for the CPU oracle (tests only)."""

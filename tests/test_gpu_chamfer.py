@@ -173,6 +173,48 @@ def test_chamfer_backward_matches_autograd_of_gathered_distance():
     np.testing.assert_allclose(yh.grad.cpu().numpy(), yr.grad.numpy(), rtol=1e-4, atol=1e-5)
 
 
+def test_chamfer_backward_is_deterministic_with_heavy_collisions():
+    """saga_chamfer_bwd is a fixed-order gather (no float atomics): many points share one neighbour (5,003 points against 37,
+    across two LDS index tiles), the result is bit-equal run to run, independent of the batch around an element, only one
+    direction's gradient may be given, and it matches float64 autograd of the gathered distances."""
+    import saga_amd.chamfer_distance as chd
+    g = torch.Generator().manual_seed(9)
+    N, P1, P2 = 3, 37, 5003
+    x = torch.randn(N, P1, 3, generator=g)
+    y = torch.randn(N, P2, 3, generator=g)
+    w1, w2 = torch.randn(N, P1, generator=g), torch.randn(N, P2, generator=g)
+
+    def run(xc, yc, a, b):
+        xh, yh = xc.cuda().requires_grad_(True), yc.cuda().requires_grad_(True)
+        h1, h2, i1, i2 = chd.ChamferDistance(xh, yh)
+        loss = 0
+        if a is not None:
+            loss = loss + (h1 * a.cuda()).sum()
+        if b is not None:
+            loss = loss + (h2 * b.cuda()).sum()
+        loss.backward()
+        return xh.grad.cpu(), yh.grad.cpu(), i1.cpu(), i2.cpu()
+
+    gx, gy, i1, i2 = run(x, y, w1, w2)
+    gx2, gy2, _, _ = run(x, y, w1, w2)
+    assert torch.equal(gx, gx2) and torch.equal(gy, gy2)
+    gx_b, gy_b, _, _ = run(x[1:2], y[1:2], w1[1:2], w2[1:2])           # element 1 alone
+    assert torch.equal(gx_b[0], gx[1]) and torch.equal(gy_b[0], gy[1])
+    xr, yr = x.double().requires_grad_(True), y.double().requires_grad_(True)
+    d1 = ((xr - yr.gather(1, i1.long()[..., None].expand(-1, -1, 3))) ** 2).sum(-1)
+    d2 = ((yr - xr.gather(1, i2.long()[..., None].expand(-1, -1, 3))) ** 2).sum(-1)
+    ((d1 * w1.double()).sum() + (d2 * w2.double()).sum()).backward()
+    np.testing.assert_allclose(gx.numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-4)    # ~135 terms per x point
+    np.testing.assert_allclose(gy.numpy(), yr.grad.numpy(), rtol=1e-4, atol=1e-5)
+    # one direction only
+    gx1, gy1, _, _ = run(x, y, None, w2)
+    xr.grad = yr.grad = None
+    d2 = ((yr - xr.gather(1, i2.long()[..., None].expand(-1, -1, 3))) ** 2).sum(-1)
+    (d2 * w2.double()).sum().backward()
+    np.testing.assert_allclose(gx1.numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gy1.numpy(), yr.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize('name', ['markers', 'rhand'])
 def test_point2point_signed_against_reference_golden(golden, name):
     """The product function on the HIP NN search against outputs of the reference's own function."""

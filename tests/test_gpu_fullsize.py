@@ -116,3 +116,46 @@ def test_pose_opt_writes_reference_schema(body_model_dir, tmp_path):
     assert np.array_equal(out2['markers_fit'], out['markers_fit'])
     assert out2['loss'].shape == (n * k,) and np.isfinite(out2['loss']).all()
     assert out2['best_of_n'].tolist() == [int(out2['loss'][:k].argmin()), k + int(out2['loss'][k:].argmin())]
+
+
+def test_config5_full_mesh_chamfer_at_full_size():
+    """BASELINE config 5 at its full size under pytest: X = 10,475 body vertices, Y = 100,000 object points, B = 512
+    (5.36e11 point pairs per direction, ~56 ms).  The CPU oracle cannot follow at this size, so: (i) a slice of batch elements
+    against the plain 6-operation exact scan kernel (a different code path, itself oracle-checked bit for bit at small sizes),
+    (ii) size-independent properties on ALL outputs: every returned distance IS the fp32 fma-chain distance to the returned
+    index, and no other point of a sampled subset is closer (or equally close with a lower index)."""
+    import os
+    import saga_amd.chamfer_distance as chd
+    B, V, P = 512, 10475, 100000
+    g = torch.Generator(device='cuda').manual_seed(0)
+    x = torch.randn(B, V, 3, device='cuda', generator=g) * torch.tensor([0.3, 0.15, 0.85], device='cuda') + torch.tensor([0., 0., 0.9], device='cuda')
+    y = torch.randn(B, P, 3, device='cuda', generator=g) * 0.25 + torch.tensor([0.3, 0.1, 1.0], device='cuda')
+    d1, d2, i1, i2 = chd.ChamferDistance(x, y)
+    torch.cuda.synchronize()
+    assert d1.shape == (B, V) and d2.shape == (B, P) and i1.dtype == torch.int32
+    assert int(i1.min()) >= 0 and int(i1.max()) < P and int(i2.min()) >= 0 and int(i2.max()) < V
+    sl = slice(100, 104)
+    os.environ['SAGA_NN_EXACT_SCAN'] = '1'
+    try:
+        r1, r2, j1, j2 = chd.ChamferDistance(x[sl].contiguous(), y[sl].contiguous())
+    finally:
+        del os.environ['SAGA_NN_EXACT_SCAN']
+    assert torch.equal(j1, i1[sl]) and torch.equal(j2, i2[sl]) and torch.equal(r1, d1[sl]) and torch.equal(r2, d2[sl])
+
+    def chain(a, b):                       # fma(dz,dz, fma(dy,dy, dx*dx)) up to fusion of the first product
+        dx, dy, dz = (a - b).unbind(-1)
+        return torch.addcmul(torch.addcmul(dx * dx, dy, dy), dz, dz)
+
+    for b0 in range(0, B, 64):             # (ii) in slabs of 64 batch elements (memory)
+        bs = slice(b0, b0 + 64)
+        near = y[bs].gather(1, i1[bs].long()[..., None].expand(-1, -1, 3))
+        assert torch.allclose(d1[bs], chain(x[bs], near), rtol=1e-6, atol=0)
+        near2 = x[bs].gather(1, i2[bs].long()[..., None].expand(-1, -1, 3))
+        assert torch.allclose(d2[bs], chain(y[bs], near2), rtol=1e-6, atol=0)
+    # no sampled database point beats the returned neighbour: 256 random queries x 4,096 random database points per element
+    qs = torch.randint(0, V, (256,), device='cuda', generator=g)
+    ps = torch.randint(0, P, (4096,), device='cuda', generator=g)
+    for b0 in range(0, B, 128):
+        bs = slice(b0, b0 + 128)
+        dd = ((x[bs][:, qs, None, :] - y[bs][:, None, ps, :]) ** 2).sum(-1)              # [128, 256, 4096]
+        assert (dd.min(dim=2).values >= d1[bs][:, qs] * (1 - 1e-6)).all()

@@ -5,7 +5,6 @@ import pytest
 import torch
 
 from oracle import chamfer_ref, geometry_ref, rotations_ref, smplx_ref, vposer_ref
-from saga_amd import rotations as prod_rot
 from saga_amd.synthetic import make_body_model, small_vertex_ids
 
 
@@ -22,16 +21,6 @@ def test_rotations_match_reference_golden(golden):
     np.testing.assert_allclose(g['aa'][0], [0.0, 2.2214415, 2.2214415], atol=1e-5)
     aa64 = rotations_ref.rotmat2aa(rotations_ref.cont2rotmat(torch.from_numpy(g['x6d']).double()))
     np.testing.assert_allclose(aa64.numpy(), g['aa64'], atol=1e-12)
-
-
-def test_product_rotations_match_reference_golden(golden):
-    """saga_amd.rotations is host-side torch code: checked on CPU against the same golden."""
-    g = golden('rotations.npz')
-    x = torch.from_numpy(g['x6d']).requires_grad_(True)
-    aa = prod_rot.RotConverter.rotmat2aa(prod_rot.RotConverter.cont2rotmat(x))
-    np.testing.assert_allclose(aa.detach().numpy(), g['aa'], rtol=0, atol=1e-6)
-    (aa * torch.from_numpy(g['w'])).sum().backward()
-    np.testing.assert_allclose(x.grad.numpy(), g['grad_x6d'], rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize('name', ['markers', 'rhand'])
