@@ -202,6 +202,17 @@ typedef struct {
     const int32_t* marker_slot;  /* [n_markers] index into unique_ids     */
     const int32_t* hand_slot;    /* [n_hand]                              */
     const int32_t* foot_slot;    /* [n_foot]                              */
+    /* Optional (all NULL / 0: not used), built by the host from the mesh's faces for saga_fit_step: the "ring" = every corner
+     * of a face that touches a hand vertex (the vertices the hand's vertex normals read), so that one small kernel can stage
+     * exactly those in LDS and produce the normals there.
+     *   ring_ids [n_ring]          ascending vertex ids of the ring (n_ring < 65,536)
+     *   hand_tri_ptr [n_hand+1], hand_tri [n_inc,2]: CSR over the hand vertices (table order) of their incident faces in
+     *                ascending face order; the three corners of a face as RING positions packed into two words:
+     *                (corner0 | corner1 << 16, corner2) */
+    int32_t n_ring;
+    const int32_t* ring_ids;
+    const int32_t* hand_tri_ptr;
+    const int32_t* hand_tri;
 } saga_grasp_tables_t;
 
 int saga_grasp_loss_fwd(const saga_model_t* m, const saga_grasp_tables_t* tables, const float* verts,

@@ -41,7 +41,9 @@ class GraspTables(ctypes.Structure):
                 ('n_body_markers', ctypes.c_int32), ('n_unique', ctypes.c_int32),
                 ('marker_ids', ctypes.c_void_p), ('hand_ids', ctypes.c_void_p), ('foot_ids', ctypes.c_void_p),
                 ('hand_weights', ctypes.c_void_p), ('unique_ids', ctypes.c_void_p), ('marker_slot', ctypes.c_void_p),
-                ('hand_slot', ctypes.c_void_p), ('foot_slot', ctypes.c_void_p)]
+                ('hand_slot', ctypes.c_void_p), ('foot_slot', ctypes.c_void_p),
+                ('n_ring', ctypes.c_int32), ('ring_ids', ctypes.c_void_p),
+                ('hand_tri_ptr', ctypes.c_void_p), ('hand_tri', ctypes.c_void_p)]
 
 
 GRASP_NTERMS = 16

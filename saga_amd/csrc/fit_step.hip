@@ -10,6 +10,7 @@
 //
 // The reference does this with ~1,400 eager kernel launches and >= 14 host syncs per iteration at batch size 1.
 #include <math.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -26,6 +27,13 @@ int saga_grasp_loss_bwd_tagged(const saga_model_t* m, const saga_grasp_tables_t*
 int saga_smplx_fwd_sel(const saga_model_t* m, const saga_model_t* sub, const float* shape, const float* full_pose, const float* transl,
                        float* vertices, float* joints, float* feat, float* rot, float* jrest, float* chain, float* A, float* v_posed,
                        float* sel_rows, int B, void* stream);
+int saga_launch_hand_ring(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* verts, float* uniq_rows,
+                          float* hand_normals, int B, void* stream);
+int saga_grasp_loss_fwd_pre(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* obj, const float* obj_normals,
+                            const float* markers_target, const float* c_markers, const float* c_object, float* terms,
+                            float* markers_rec, float* hand_rec, float* hand_normals, const float* uniq_rows, float* h2o_marker,
+                            float* h2o_signed, float* o2h_signed, int32_t* idx_m2o, int32_t* idx_h2o, int32_t* idx_o2h, int B, int O,
+                            void* stream);
 int saga_grasp_loss_fwd_rec(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* verts, const float* markers_target,
                             float* terms, float* markers_rec, int32_t* idx_m2o, int B, void* stream);
 int saga_launch_gemm_nt(int epi, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, const float* bias,
@@ -107,7 +115,7 @@ extern "C" int saga_decoder_create(saga_decoder_t** out, const saga_decoder_desc
 struct FitWs {
     float *h1, *h2, *x6, *jac, *shape, *full_pose, *transl;               // parameter maps
     float *feat, *rot, *jrest, *chain, *A, *v_posed, *verts, *joints;     // SMPL-X forward
-    float *terms, *g_terms, *hand_rec, *hand_nrm, *h2o_marker, *h2o_signed, *o2h_signed;
+    float *terms, *g_terms, *hand_rec, *hand_nrm, *h2o_marker, *h2o_signed, *o2h_signed, *uniq_rows;
     int32_t *idx_m2o, *idx_h2o, *idx_o2h;
     float *g_verts, *gvp, *slab, *dA, *g_shape, *g_pose, *g_transl;       // SMPL-X backward
     float *g_x6, *g_h, *g_z, *grad;                                       // reverse parameter maps
@@ -134,6 +142,7 @@ static FitWs fit_ws_carve(float* base, const saga_model* m, const saga_grasp_tab
     w.A = take(b * NJ * 12); w.v_posed = take(b * Npad); w.verts = take(b * V * 3); w.joints = take(b * njo * 3);
     w.terms = take(b * NTERM); w.g_terms = take(b * NTERM); w.hand_rec = take(b * H * 3); w.hand_nrm = take(b * H * 3);
     w.h2o_marker = take(b * M); w.h2o_signed = take(b * H); w.o2h_signed = take(b * O);
+    w.uniq_rows = take(b * (tb ? tb->n_unique : 0) * 3);
     w.idx_m2o = (int32_t*)take(b * M); w.idx_h2o = (int32_t*)take(b * H); w.idx_o2h = (int32_t*)take(b * O);
     w.g_verts = take(b * V * 3); w.gvp = take(b * Npad); w.slab = take((size_t)SAGA_BWD_SPLITK * b * FEAT_K);
     w.dA = take(b * SAGA_DA_STRIDE); w.g_shape = take(b * (S > 0 ? S : 1)); w.g_pose = take(b * 165); w.g_transl = take(b * 3);
@@ -438,7 +447,7 @@ static int fit_step_impl(const saga_model_t* m, const saga_model_t* mb, const sa
     // what the carve above depends on (+ the table set the zero-fill marks are for); never 0, the value a fresh workspace holds
     uint64_t lh = 0xCBF29CE484222325ull;
     for (uint64_t x : {(uint64_t)B, (uint64_t)O, (uint64_t)m->V, (uint64_t)m->Npad, (uint64_t)m->S, (uint64_t)(m->E + m->L),
-                       (uint64_t)tb->n_markers, (uint64_t)tb->n_hand, (uint64_t)tb->n_unique, (uint64_t)(uintptr_t)tb->unique_ids,
+                       (uint64_t)tb->n_markers, (uint64_t)tb->n_hand, (uint64_t)tb->n_foot, (uint64_t)tb->n_unique, (uint64_t)(uintptr_t)tb->unique_ids,
                        (uint64_t)(uintptr_t)ws})
         lh = (lh ^ x) * 0x100000001B3ull;
     int32_t layout = (int32_t)(lh ^ (lh >> 32));
@@ -453,14 +462,28 @@ static int fit_step_impl(const saga_model_t* m, const saga_model_t* mb, const sa
     }
     // sparse backward: the skinning forward also writes the v_posed rows of the loss vertices, compact, for the subset backward
     float* vps = mb ? w.gvp + (size_t)B * mb->Npad : nullptr;
-    if ((rc = saga_smplx_fwd_sel(m, mb, w.shape, w.full_pose, w.transl, w.verts, w.joints, w.feat, w.rot, w.jrest, w.chain, w.A,
-                                 w.v_posed, vps, B, stream)))
-        return rc;
     // every contact / collision term has weight 0 in stages 0 and 1 (and with only_rec): the reference still evaluates and logs
     // them; with skip_gated_terms they are neither evaluated nor logged (written as 0) -- no NN scan, no hand normals
     const bool gated_off = cfg->skip_gated_terms && (cfg->stage < 2 || cfg->only_rec);
+    if ((rc = saga_smplx_fwd_sel(m, mb, w.shape, w.full_pose, w.transl, w.verts, w.joints, w.feat, w.rot, w.jrest, w.chain, w.A,
+                                 w.v_posed, vps, B, stream)))
+        return rc;
+    // One small kernel stages the hand's face ring in LDS, takes the hand normals from there and writes the vertices the loss reads
+    // as compact rows; the loss kernel then touches neither the mesh nor its faces (tables with the optional ring fields).
+    // SAGA_FIT_NO_PRE=1: the loss kernel gathers and builds the normals by itself -- the cross-check path, same results bit for bit.
+    int pre_done = 0;
+    if (!gated_off && O <= 2048 && m->F > 0 && getenv("SAGA_FIT_NO_PRE") == nullptr) {
+        rc = saga_launch_hand_ring(m, tb, w.verts, w.uniq_rows, w.hand_nrm, B, stream);
+        if (rc != 0 && rc != 1) return rc;
+        pre_done = rc == 0;
+    }
     if (gated_off) {
         if ((rc = saga_grasp_loss_fwd_rec(m, tb, w.verts, prob->markers_target, w.terms, markers_rec, w.idx_m2o, B, stream))) return rc;
+    } else if (pre_done) {
+        if ((rc = saga_grasp_loss_fwd_pre(m, tb, prob->obj, prob->obj_normals, prob->markers_target, prob->c_markers, prob->c_object,
+                                          w.terms, markers_rec, w.hand_rec, w.hand_nrm, w.uniq_rows, w.h2o_marker, w.h2o_signed,
+                                          w.o2h_signed, w.idx_m2o, w.idx_h2o, w.idx_o2h, B, O, stream)))
+            return rc;
     } else if ((rc = saga_grasp_loss_fwd(m, tb, w.verts, prob->obj, prob->obj_normals, prob->markers_target, prob->c_markers,
                                          prob->c_object, w.terms, markers_rec, w.hand_rec, w.hand_nrm, w.h2o_marker, w.h2o_signed,
                                          w.o2h_signed, w.idx_m2o, w.idx_h2o, w.idx_o2h, B, O, stream)))

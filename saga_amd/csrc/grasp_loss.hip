@@ -224,6 +224,10 @@ extern "C" int saga_debug_read_phases(unsigned long long* out) {
 #ifndef GL_NRM_FPS
 #define GL_NRM_FPS 2             // faces per vertex and gather step of the hand normals (3: 1.22 ms against 1.10, registers)
 #endif
+// PRE (saga_fit_step): the vertices the loss reads come as compact rows uniq_rows [B, n_unique, 3] (markers / hand / feet through
+// the tables' *_slot arrays) and hand_normals is an INPUT -- both written by the whole-candidate skinning kernel (skin.hip,
+// skin_fwd_cand_kernel); this kernel then touches neither the mesh nor its faces.
+template <bool PRE>
 __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     saga_grasp_tables_t tb, const float* __restrict__ verts, const int32_t* __restrict__ vf_ptr,
     const int32_t* __restrict__ vf_tri, const float* __restrict__ obj,
@@ -231,21 +235,35 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     const float* __restrict__ c_obj, float* __restrict__ terms, float* __restrict__ markers_rec,
     float* __restrict__ hand_rec, float* __restrict__ hand_normals, float* __restrict__ h2o_marker,
     float* __restrict__ h2o_signed, float* __restrict__ o2h_signed, int32_t* __restrict__ idx_m2o,
-    int32_t* __restrict__ idx_h2o, int32_t* __restrict__ idx_o2h, int V, int O, int touch_verts) {
+    int32_t* __restrict__ idx_h2o, int32_t* __restrict__ idx_o2h, int V, int O, int touch_verts, const float* __restrict__ uniq_rows) {
 #pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) float sObj[NNF_TILE_FLOATS(GL_TILE)];        // framed object tile; later the hand normals
-    __shared__ __attribute__((aligned(16))) float sHand[NNF_TILE_FLOATS(GL_MAX_HAND)];   // framed hand tile
+    // One LDS arena (52 KB: three blocks per CU), used in two phases.
+    //   hand/markers -> object:  [ framed object tile (f32) | A operands of 16 object tiles at a time ]
+    //   object -> hand:          [ A operands of every hand tile | hand normals | ... | framed hand tile (f32), at the arena's end ]
+    constexpr int SM_OBJ = NNF_TILE_FLOATS(GL_TILE), SM_TOTAL = SM_OBJ + NNF_TILE_FLOATS(GL_MAX_HAND);
+    __shared__ __attribute__((aligned(16))) float smem[SM_TOTAL];
     __shared__ float red[GL_THREADS / 64][GL_NSUM];
     __shared__ float sbox[6 * (GL_THREADS / 64)];
-    float* sNrm = sObj;
+    float* const sObj = smem;
+    float* const sImgO = smem + SM_OBJ;
     // candidates in reverse launch order: the producer (skinning) wrote them in ascending order, so the most recently
     // written vertices -- the ones still in the Infinity Cache -- are read first
     const int b = gridDim.x - 1 - blockIdx.x, tid = threadIdx.x;
     const int H = tb.n_hand, M = tb.n_markers, NQ = H + M;
-    const int Hpad = (H + NNF_CH - 1) / NNF_CH * NNF_CH;
+    const int Hpad = (H + 31) & ~31;           // both clouds are padded with far points to whole 32-point matrix tiles
+    // phase 2 layout: the hand tile sits at the arena's end; its A-operand image (1 KB per 32 vertices) and the normals in front of
+    // it when they fit (H <= ~830; beyond, every wave builds the hand's A operands itself)
+    const int h_tiles = Hpad >> 5;
+    const int hand_off = (SM_TOTAL - NNF_TILE_FLOATS(Hpad)) & ~3;
+    const int nrm_floats = (H * 3 + 3) & ~3;
+    const bool a_image = h_tiles * 256 + nrm_floats <= hand_off;
+    float* const sHand = smem + hand_off;
+    float* const sAimg = smem;
+    float* const sNrm = smem + (a_image ? h_tiles * 256 : 0);
     const float* vb = verts + (size_t)b * V * 3;
     const float* ob = obj + (size_t)b * O * 3;
     const float* onb = obj_n + (size_t)b * O * 3;
+    const int wave = tid >> 6, lane = tid & 63;
     GL_T0();
 
     // the lane's object points (O <= GL_TILE = GL_OPL * GL_THREADS): requested first, together with the query gathers below, and
@@ -260,19 +278,29 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     // ---- x -> y queries: lane owns hand vertices / markers q = tid + i*GL_THREADS, i < GL_NQ ------------------
     float qx[GL_NQ], qy[GL_NQ], qz[GL_NQ];
     float hlo[3] = {INFINITY, INFINITY, INFINITY}, hhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float mlo[3] = {INFINITY, INFINITY, INFINITY}, mhi[3] = {-INFINITY, -INFINITY, -INFINITY};      // the markers' box
 #pragma unroll
     for (int i = 0; i < GL_NQ; ++i) {
         const int q = tid + i * GL_THREADS;
         const int qc = min(q, NQ - 1);
-        const int v = qc < H ? tb.hand_ids[qc] : tb.marker_ids[qc - H];
-        qx[i] = vb[v * 3]; qy[i] = vb[v * 3 + 1]; qz[i] = vb[v * 3 + 2];
+        float* rec = qc < H ? hand_rec + ((size_t)b * H + qc) * 3 : markers_rec + ((size_t)b * M + (qc - H)) * 3;
+        if (PRE) {
+            const float* u = uniq_rows + ((size_t)b * tb.n_unique + (qc < H ? tb.hand_slot[qc] : tb.marker_slot[qc - H])) * 3;
+            qx[i] = u[0]; qy[i] = u[1]; qz[i] = u[2];
+        } else {
+            const int v = qc < H ? tb.hand_ids[qc] : tb.marker_ids[qc - H];
+            qx[i] = vb[v * 3]; qy[i] = vb[v * 3 + 1]; qz[i] = vb[v * 3 + 2];
+        }
         if (q < NQ) {
-            float* dst = q < H ? hand_rec + ((size_t)b * H + q) * 3 : markers_rec + ((size_t)b * M + (q - H)) * 3;
-            dst[0] = qx[i]; dst[1] = qy[i]; dst[2] = qz[i];
+            rec[0] = qx[i]; rec[1] = qy[i]; rec[2] = qz[i];
             if (q < H) {
                 hlo[0] = fminf(hlo[0], qx[i]); hhi[0] = fmaxf(hhi[0], qx[i]);
                 hlo[1] = fminf(hlo[1], qy[i]); hhi[1] = fmaxf(hhi[1], qy[i]);
                 hlo[2] = fminf(hlo[2], qz[i]); hhi[2] = fmaxf(hhi[2], qz[i]);
+            } else {
+                mlo[0] = fminf(mlo[0], qx[i]); mhi[0] = fmaxf(mhi[0], qx[i]);
+                mlo[1] = fminf(mlo[1], qy[i]); mhi[1] = fmaxf(mhi[1], qy[i]);
+                mlo[2] = fminf(mlo[2], qz[i]); mhi[2] = fmaxf(mhi[2], qz[i]);
             }
         }
     }
@@ -286,20 +314,20 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
         olo[2] = fminf(olo[2], op[i].z); ohi[2] = fmaxf(ohi[2], op[i].z);
     }
     const NnfFrame fo = nnf_frame_from_box(olo, ohi, sbox, tid, GL_THREADS);
+    // the hand's frame, and the box of ALL queries (hand + markers) in the object's frame: one scale of the matrix-core pass for
+    // the whole block (nnf_scales' rq: any upper bound of the framed queries' largest |coordinate|), so its A operands can be shared
+    float qlo[3], qhi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { qlo[a] = fminf(hlo[a], mlo[a]); qhi[a] = fmaxf(hhi[a], mhi[a]); }
     const NnfFrame fh = nnf_frame_from_box(hlo, hhi, sbox, tid, GL_THREADS);
-    const int Opad = (O + NNF_CH - 1) / NNF_CH * NNF_CH;
+    const NnfFrame fq = nnf_frame_from_box(qlo, qhi, sbox, tid, GL_THREADS);      // .rp >= half diagonal of the queries' box about (.cx,.cy,.cz)
+    const int Opad = (O + 31) & ~31;
 #pragma unroll
     for (int i = 0; i < GL_OPL; ++i) {
         const int k = tid + i * GL_THREADS;
         if (k < O) nnf_store_point(sObj, k, op[i].x, op[i].y, op[i].z, fo);
         else if (k < Opad) nnf_store_point(sObj, k, NN_FAR, NN_FAR, NN_FAR, fo);
     }
-#pragma unroll
-    for (int i = 0; i < GL_NQ; ++i) {
-        const int q = tid + i * GL_THREADS;
-        if (q < H) nnf_store_point(sHand, q, qx[i], qy[i], qz[i], fh);
-    }
-    for (int q = H + tid; q < Hpad; q += GL_THREADS) nnf_store_point(sHand, q, NN_FAR, NN_FAR, NN_FAR, fh);
     __syncthreads();
     GL_T(1);
 
@@ -315,8 +343,38 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
         for (int i = 0; i < GL_NQ; ++i) { cx[i] = qx[i] - fo.cx; cy[i] = qy[i] - fo.cy; cz[i] = qz[i] - fo.cz; }
 #pragma unroll
         for (int i = 0; i < GL_NQ; ++i) { best[i] = INFINITY; bi[i] = 0; }
-        // approximate pass on the matrix cores (f16-split operands, nn_fast.h), exact pass on the two candidate chunks
-        nnf_scan_mfma<GL_NQ>(sObj, Opad / NNF_CH, fo, cx, cy, cz, m1, m2, m3, c1, c2);
+        // approximate pass on the matrix cores (f16-split operands, nn_fast.h), exact pass on the two candidate chunks.  The four
+        // waves scan the same 64 object tiles: their A operands are built ONCE per block, 16 tiles (16 KB) at a time, into the LDS
+        // the hand tile will take afterwards (a wave rebuilding all of them itself spent a quarter of this scan's instructions there)
+        {
+            const float rq = fq.rp + fmaxf(fabsf(fq.cx - fo.cx), fmaxf(fabsf(fq.cy - fo.cy), fabsf(fq.cz - fo.cz)));
+            const NnfScales ko = nnf_scales(fo.rp, rq);
+            // query tile (i, hh) of this wave starts at query wave*64 + hh*32 + i*256: all-padding tiles are skipped
+            unsigned act = 0;
+#pragma unroll
+            for (int i = 0; i < GL_NQ; ++i)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+                    if (wave * 64 + hh * 32 + i * GL_THREADS < NQ) act |= 1u << (2 * i + hh);
+            NnfMfmaState<GL_NQ> st;
+            nnf_mfma_begin<GL_NQ>(st, ko, cx, cy, cz);
+            constexpr int IMG_TILES = 16;
+            static_assert(IMG_TILES * 256 <= NNF_TILE_FLOATS(GL_MAX_HAND), "the A-operand image lives behind the object tile");
+            const int o_tiles = Opad >> 5;
+#ifdef GL_EXP_XY_PRIVATE        // timing experiment (scripts/exp): every wave builds its own A operands, no rounds, no barriers
+            nnf_mfma_tiles<GL_NQ, false, true>(st, sObj, Opad / NNF_CH, 0, o_tiles, 0, ko, act);
+#else
+            for (int r = 0; r < o_tiles; r += IMG_TILES) {
+                const int r1 = min(r + IMG_TILES, o_tiles);
+                if (r) __syncthreads();
+                for (int t = r + wave; t < r1; t += GL_THREADS / 64)
+                    reinterpret_cast<nn_h8*>(sImgO)[(t - r) * 64 + lane] = nnf_build_A(sObj, Opad, t, lane, ko);
+                __syncthreads();
+                nnf_mfma_tiles<GL_NQ, true, true>(st, sImgO, Opad / NNF_CH, r, r1, r, ko, act);
+            }
+#endif
+            nnf_mfma_end<GL_NQ>(st, ko, m1, m2, m3, c1, c2);
+        }
         GL_T(2);
         nnf_resolve<GL_NQ, true>(sObj, Opad / NNF_CH, fo, 0, cx, cy, cz, qx, qy, qz, m1, m2, m3, c1, c2, best, bi);
         GL_T(3);
@@ -355,7 +413,8 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
         }
     }
     // foot term: 0.1 * mean |z| (:173)
-    for (int i = tid; i < tb.n_foot; i += GL_THREADS) sums[2] += fabsf(vb[tb.foot_ids[i] * 3 + 2]);
+    for (int i = tid; i < tb.n_foot; i += GL_THREADS)
+        sums[2] += fabsf(PRE ? uniq_rows[((size_t)b * tb.n_unique + tb.foot_slot[i]) * 3 + 2] : vb[tb.foot_ids[i] * 3 + 2]);
 
     GL_T(4);
     // ---- hand normals (area-weighted, ascending face order) into the LDS space the object tile no longer needs ----
@@ -363,22 +422,38 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     // (touch_verts: set by the host from the model's faces), those are ~14k scattered 12-B reads per candidate that miss L2
     // (4x the bytes the candidate has).  Touching every 128-B line of the candidate's vertex block once, coalesced, brings
     // the block (126 KB) into L2 first.
-    if (touch_verts) {
+#ifndef GL_EXP_NO_NORMALS
+    if (!PRE && touch_verts) {
         const int n_lines = (V * 3 + 31) / 32;
         for (int l = tid; l < n_lines; l += GL_THREADS) {
             const float x = vb[min(l * 32, V * 3 - 1)];
             asm volatile("" ::"v"(x));
         }
     }
-    __syncthreads();
-    {
+#endif
+    __syncthreads();                          // every wave is done with the object tile and its A-operand image: phase 2 of the arena
+#pragma unroll
+    for (int i = 0; i < GL_NQ; ++i) {
+        const int q = tid + i * GL_THREADS;
+        if (q < H) nnf_store_point(sHand, q, qx[i], qy[i], qz[i], fh);
+    }
+    for (int q = H + tid; q < Hpad; q += GL_THREADS) nnf_store_point(sHand, q, NN_FAR, NN_FAR, NN_FAR, fh);
+    if (PRE) {
+        const float* hn = hand_normals + (size_t)b * H * 3;
+        for (int i = tid; i < H * 3; i += GL_THREADS) sNrm[i] = hn[i];
+    } else {
         // all of a lane's hand vertices (GL_MAX_HAND / GL_THREADS = 4) at once: their read chains advance together
         constexpr int NVL = GL_MAX_HAND / GL_THREADS;
         int hv[NVL];
         float nr[NVL][3];
 #pragma unroll
         for (int r = 0; r < NVL; ++r) hv[r] = (tid + r * GL_THREADS < H) ? tb.hand_ids[tid + r * GL_THREADS] : -1;
+#ifdef GL_EXP_NO_NORMALS            // timing experiment only (scripts/exp): what the kernel costs without the normals' gathers
+#pragma unroll
+        for (int r = 0; r < NVL; ++r) { nr[r][0] = 0.f; nr[r][1] = 0.f; nr[r][2] = 1.f; }
+#else
         saga_vertex_normals_multi<NVL, GL_NRM_FPS>(vb, vf_ptr, vf_tri, hv, nr);
+#endif
 #pragma unroll
         for (int r = 0; r < NVL; ++r) {
             const int i = tid + r * GL_THREADS;
@@ -391,10 +466,8 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     // The hand tile is scanned once per pass below by every wave: its A operands (matrix-core pass, nn_fast.h) are built once
     // per block into the rest of the LDS space the object tile no longer needs (1 KB per 32 hand vertices, after the normals),
     // with one scale for the whole block: every object point is within fo.rp of the object frame's centre.
-    const int h_tiles = (Hpad / NNF_CH + 1) >> 1;
-    float* sAimg = sNrm + ((H * 3 + 3) & ~3);
-    const bool a_image = (size_t)(((H * 3 + 3) & ~3) + h_tiles * 256) * sizeof(float) <= sizeof(sObj);
     const NnfScales kh = nnf_scales(fh.rp, fo.rp * 1.0001f + fmaxf(fabsf(fo.cx - fh.cx), fmaxf(fabsf(fo.cy - fh.cy), fabsf(fo.cz - fh.cz))));
+    if (a_image) __syncthreads();             // the hand tile is complete
     if (a_image)
         for (int t = tid >> 6; t < h_tiles; t += GL_THREADS / 64)
             reinterpret_cast<nn_h8*>(sAimg)[t * 64 + (tid & 63)] = nnf_build_A(sHand, Hpad, t, tid & 63, kh);
@@ -411,8 +484,19 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
             ox[i] = ob[k * 3]; oy[i] = ob[k * 3 + 1]; oz[i] = ob[k * 3 + 2];
             cx[i] = ox[i] - fh.cx; cy[i] = oy[i] - fh.cy; cz[i] = oz[i] - fh.cz;
         }
-        if (a_image) nnf_scan_mfma_core<GLF_NO, true>(sAimg, Hpad / NNF_CH, kh, cx, cy, cz, m1, m2, m3, c1, c2);
-        else nnf_scan_mfma_core<GLF_NO, false>(sHand, Hpad / NNF_CH, kh, cx, cy, cz, m1, m2, m3, c1, c2);
+        {
+            unsigned act = 0;
+#pragma unroll
+            for (int i = 0; i < GLF_NO; ++i)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+                    if (k0 + wave * 64 + hh * 32 + i * GL_THREADS < O) act |= 1u << (2 * i + hh);
+            NnfMfmaState<GLF_NO> st;
+            nnf_mfma_begin<GLF_NO>(st, kh, cx, cy, cz);
+            if (a_image) nnf_mfma_tiles<GLF_NO, true, true>(st, sAimg, Hpad / NNF_CH, 0, h_tiles, 0, kh, act);
+            else nnf_mfma_tiles<GLF_NO, false, true>(st, sHand, Hpad / NNF_CH, 0, h_tiles, 0, kh, act);
+            nnf_mfma_end<GLF_NO>(st, kh, m1, m2, m3, c1, c2);
+        }
 #pragma unroll
         for (int i = 0; i < GLF_NO; ++i) { best[i] = INFINITY; bj[i] = 0; }
         nnf_resolve<GLF_NO, true>(sHand, Hpad / NNF_CH, fh, 0, cx, cy, cz, ox, oy, oz, m1, m2, m3, c1, c2, best, bj);
@@ -437,7 +521,6 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
 
     GL_T(6);
     // ---- per-candidate means: wave shuffles, then the four wave partials in wave order ---------------------
-    const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
     for (int i = 0; i < GL_NSUM; ++i) {
         float v = sums[i];
@@ -635,15 +718,41 @@ extern "C" int saga_grasp_loss_fwd(const saga_model_t* m, const saga_grasp_table
                    "saga_grasp_loss_fwd: null buffer");
     void* prof = saga_prof_begin(SAGA_PROF_GRASP_FWD, stream);
     if (O <= GL_TILE)
-        grasp_loss_fwd_fast_kernel<<<B, GL_THREADS, 0, (hipStream_t)stream>>>(*tb, verts, m->vf_ptr, m->vf_tri, obj,
+        grasp_loss_fwd_fast_kernel<false><<<B, GL_THREADS, 0, (hipStream_t)stream>>>(*tb, verts, m->vf_ptr, m->vf_tri, obj,
                                                                               obj_normals, markers_target, c_markers, c_object, terms,
                                                                               markers_rec, hand_rec, hand_normals, h2o_marker,
-                                                                              h2o_signed, o2h_signed, idx_m2o, idx_h2o, idx_o2h, m->V, O, m->scattered_faces);
+                                                                              h2o_signed, o2h_signed, idx_m2o, idx_h2o, idx_o2h, m->V, O, m->scattered_faces, nullptr);
     else
         grasp_loss_fwd_kernel<<<B, GL_THREADS, 0, (hipStream_t)stream>>>(*tb, verts, m->vf_ptr, m->vf_tri, obj, obj_normals,
                                                                          markers_target, c_markers, c_object, terms, markers_rec,
                                                                          hand_rec, hand_normals, h2o_marker, h2o_signed, o2h_signed,
                                                                          idx_m2o, idx_h2o, idx_o2h, m->V, O);
+    saga_prof_end(prof);
+    SAGA_LAUNCH_CHECK();
+    return 0;
+}
+
+// saga_fit_step after saga_launch_skin_fwd_cand: uniq_rows and hand_normals are inputs (see the kernel).
+// O <= GL_TILE only (the caller falls back to saga_grasp_loss_fwd otherwise).
+int saga_grasp_loss_fwd_pre(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* obj, const float* obj_normals,
+                            const float* markers_target, const float* c_markers, const float* c_object, float* terms,
+                            float* markers_rec, float* hand_rec, float* hand_normals, const float* uniq_rows, float* h2o_marker,
+                            float* h2o_signed, float* o2h_signed, int32_t* idx_m2o, int32_t* idx_h2o, int32_t* idx_o2h, int B, int O,
+                            void* stream) {
+    SAGA_CHECK_ARG(m, "saga_grasp_loss_fwd_pre: null model");
+    SAGA_CHECK_DEVICE(m, "saga_grasp_loss_fwd_pre");
+    int rc = check_tables(tb);
+    if (rc) return rc;
+    SAGA_CHECK_ARG(B >= 0 && O > 0 && O <= GL_TILE, "saga_grasp_loss_fwd_pre: bad sizes B=%d O=%d", B, O);
+    if (B == 0) return 0;
+    SAGA_CHECK_ARG(obj && obj_normals && markers_target && c_markers && c_object && terms && markers_rec && hand_rec && hand_normals &&
+                       uniq_rows && h2o_marker && h2o_signed && o2h_signed && idx_m2o && idx_h2o && idx_o2h,
+                   "saga_grasp_loss_fwd_pre: null buffer");
+    void* prof = saga_prof_begin(SAGA_PROF_GRASP_FWD, stream);
+    grasp_loss_fwd_fast_kernel<true><<<B, GL_THREADS, 0, (hipStream_t)stream>>>(*tb, nullptr, m->vf_ptr, m->vf_tri, obj, obj_normals,
+                                                                                markers_target, c_markers, c_object, terms, markers_rec,
+                                                                                hand_rec, hand_normals, h2o_marker, h2o_signed, o2h_signed,
+                                                                                idx_m2o, idx_h2o, idx_o2h, m->V, O, 0, uniq_rows);
     saga_prof_end(prof);
     SAGA_LAUNCH_CHECK();
     return 0;

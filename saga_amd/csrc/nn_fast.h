@@ -267,17 +267,27 @@ __device__ __forceinline__ nn_h8 nnf_build_A(const float* __restrict__ s, int n_
     return h ? ahi : alo;
 }
 
-// The scan proper.  IMAGE = false: s is the framed f32 tile, every wave builds its A operands as it goes.  IMAGE = true: s is
-// an LDS image of the A operands ([tile][lane] nn_h8, built once per block with nnf_build_A and THESE scales) -- for callers
-// that scan the same tile several times and have the LDS for it.
-template <int NQ, bool IMAGE>
-__device__ __forceinline__ void nnf_scan_mfma_core(const float* __restrict__ s, int n_chunks, const NnfScales& k, const float (&qx)[NQ],
-                                                   const float (&qy)[NQ], const float (&qz)[NQ], float (&m1)[NQ], float (&m2)[NQ],
-                                                   float (&m3)[NQ], int (&c1)[NQ], int (&c2)[NQ]) {
-    const int lane = __lane_id(), col = lane & 31, h = lane >> 5;
-    const float sq = k.sq, inv_S = k.inv_S;
-    // B operands: tile (i, hh) = query i of lanes hh*32 .. hh*32+31
+// The scan proper, in three steps so that a caller can feed the tiles in rounds (e.g. an LDS image of the A operands that only
+// holds a part of the cloud at a time): nnf_mfma_begin (B operands of the lane's queries, empty sorted triples), nnf_mfma_tiles
+// (any number of calls, tiles in any order: chunk ids are global), nnf_mfma_end (the two lanes that share a query merge).
+// IMAGE = false: s is the framed f32 tile, every wave builds its A operands as it goes.  IMAGE = true: s is an LDS image of
+// the A operands ([tile - img_tile0][lane] nn_h8, built with nnf_build_A and THESE scales) -- for callers whose waves scan
+// the same tile and have the LDS for it.  EVEN: the cloud is padded with far points to a whole number of 32-point tiles
+// (n_chunks even), so no half tile has to be masked.  act: bit (2 i + hh) = query tile (i, hh) holds at least one real
+// query (wave-uniform); the matrix instruction and the bookkeeping of an all-padding query tile are skipped.
+template <int NQ>
+struct NnfMfmaState {
     nn_h8 Bq[NQ][2];
+    float M1[NQ][2], M2[NQ][2], M3[NQ][2];
+    int C1[NQ][2], C2[NQ][2];
+};
+
+template <int NQ>
+__device__ __forceinline__ void nnf_mfma_begin(NnfMfmaState<NQ>& st, const NnfScales& k, const float (&qx)[NQ], const float (&qy)[NQ],
+                                               const float (&qz)[NQ]) {
+    const int lane = __lane_id(), col = lane & 31, h = lane >> 5;
+    const float sq = k.sq;
+    // B operands: tile (i, hh) = query i of lanes hh*32 .. hh*32+31
     const _Float16 one = (_Float16)1.f;
 #pragma unroll
     for (int i = 0; i < NQ; ++i)
@@ -289,53 +299,82 @@ __device__ __forceinline__ void nnf_scan_mfma_core(const float* __restrict__ s, 
             nnf_split16(__shfl(qy[i], src, 64) * sq, yh, yl);
             nnf_split16(__shfl(qz[i], src, 64) * sq, zh, zl);
             const nn_h8 lo = {xh, yh, zh, xl, yl, zl, xh, yh}, hi = {zh, one, one, one, xl, yl, zl, one};
-            Bq[i][hh] = h ? hi : lo;
+            st.Bq[i][hh] = h ? hi : lo;
+            st.M1[i][hh] = INFINITY; st.M2[i][hh] = INFINITY; st.M3[i][hh] = INFINITY; st.C1[i][hh] = -1; st.C2[i][hh] = -1;
         }
-    float M1[NQ][2], M2[NQ][2], M3[NQ][2];
-    int C1[NQ][2], C2[NQ][2];
-#pragma unroll
-    for (int i = 0; i < NQ; ++i)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) { M1[i][hh] = INFINITY; M2[i][hh] = INFINITY; M3[i][hh] = INFINITY; C1[i][hh] = -1; C2[i][hh] = -1; }
+}
 
-    const int n_pts = n_chunks * NNF_CH, n_tiles = (n_chunks + 1) >> 1;
+template <int NQ, bool IMAGE, bool EVEN>
+__device__ __forceinline__ void nnf_mfma_tiles(NnfMfmaState<NQ>& st, const float* __restrict__ s, int n_chunks, int tile_lo, int tile_hi,
+                                               int img_tile0, const NnfScales& k, unsigned act) {
+    const int lane = __lane_id(), h = lane >> 5;
+    const int n_pts = n_chunks * NNF_CH;
     const nn_f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int tile = 0; tile < n_tiles; ++tile) {
-        const nn_h8 A = IMAGE ? reinterpret_cast<const nn_h8*>(s)[tile * 64 + lane] : nnf_build_A(s, n_pts, tile, lane, k);
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+        const nn_h8 A = IMAGE ? reinterpret_cast<const nn_h8*>(s)[(tile - img_tile0) * 64 + lane] : nnf_build_A(s, n_pts, tile, lane, k);
         const int c = 2 * tile + h;
-        const bool valid = c < n_chunks;
+        const bool valid = EVEN || c < n_chunks;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             // two MFMAs in flight, then their two reductions; the scheduling fence keeps the compiler from issuing all 2 NQ
             // MFMAs first (16 accumulator registers each)
-            const nn_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, Bq[i][0], zero16, 0, 0, 0);
-            const nn_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, Bq[i][1], zero16, 0, 0, 0);
-            // v_minimum3_f32 (IEEE-754-2019 minimum: no canonicalisation of the accumulator registers needed)
-            float ma = __builtin_elementwise_minimum(D0[0], D0[1]), mb = __builtin_elementwise_minimum(D1[0], D1[1]);
+            const bool a0 = (act >> (2 * i)) & 1u, a1 = (act >> (2 * i + 1)) & 1u;
+            if (a0 && a1) {
+                const nn_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, st.Bq[i][0], zero16, 0, 0, 0);
+                const nn_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, st.Bq[i][1], zero16, 0, 0, 0);
+                // v_minimum3_f32 (IEEE-754-2019 minimum: no canonicalisation of the accumulator registers needed)
+                float ma = __builtin_elementwise_minimum(D0[0], D0[1]), mb = __builtin_elementwise_minimum(D1[0], D1[1]);
 #pragma unroll
-            for (int r = 2; r < 16; r += 2) ma = __builtin_elementwise_minimum(__builtin_elementwise_minimum(ma, D0[r]), D0[r + 1]);
+                for (int r = 2; r < 16; r += 2) ma = __builtin_elementwise_minimum(__builtin_elementwise_minimum(ma, D0[r]), D0[r + 1]);
 #pragma unroll
-            for (int r = 2; r < 16; r += 2) mb = __builtin_elementwise_minimum(__builtin_elementwise_minimum(mb, D1[r]), D1[r + 1]);
-            ma = valid ? ma : INFINITY;
-            mb = valid ? mb : INFINITY;
-            nnf_insert3(ma, c, M1[i][0], M2[i][0], M3[i][0], C1[i][0], C2[i][0]);
-            nnf_insert3(mb, c, M1[i][1], M2[i][1], M3[i][1], C1[i][1], C2[i][1]);
+                for (int r = 2; r < 16; r += 2) mb = __builtin_elementwise_minimum(__builtin_elementwise_minimum(mb, D1[r]), D1[r + 1]);
+                if (!EVEN) { ma = valid ? ma : INFINITY; mb = valid ? mb : INFINITY; }
+                nnf_insert3(ma, c, st.M1[i][0], st.M2[i][0], st.M3[i][0], st.C1[i][0], st.C2[i][0]);
+                nnf_insert3(mb, c, st.M1[i][1], st.M2[i][1], st.M3[i][1], st.C1[i][1], st.C2[i][1]);
+            } else if (a0 || a1) {
+                const int hh = a0 ? 0 : 1;
+                const nn_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, a0 ? st.Bq[i][0] : st.Bq[i][1], zero16, 0, 0, 0);
+                float ma = __builtin_elementwise_minimum(D0[0], D0[1]);
+#pragma unroll
+                for (int r = 2; r < 16; r += 2) ma = __builtin_elementwise_minimum(__builtin_elementwise_minimum(ma, D0[r]), D0[r + 1]);
+                if (!EVEN) ma = valid ? ma : INFINITY;
+                if (hh == 0) nnf_insert3(ma, c, st.M1[i][0], st.M2[i][0], st.M3[i][0], st.C1[i][0], st.C2[i][0]);
+                else nnf_insert3(ma, c, st.M1[i][1], st.M2[i][1], st.M3[i][1], st.C1[i][1], st.C2[i][1]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+}
+
+template <int NQ>
+__device__ __forceinline__ void nnf_mfma_end(const NnfMfmaState<NQ>& st, const NnfScales& k, float (&m1)[NQ], float (&m2)[NQ],
+                                             float (&m3)[NQ], int (&c1)[NQ], int (&c2)[NQ]) {
+    const int h = __lane_id() >> 5;
+    const float inv_S = k.inv_S;
     // the lane's own query i was scanned in tile (i, h): its rows by this lane, the other 16 of every 32 by lane ^ 32
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-        float a1 = h ? M1[i][1] : M1[i][0], a2 = h ? M2[i][1] : M2[i][0], a3 = h ? M3[i][1] : M3[i][0];
-        int k1 = h ? C1[i][1] : C1[i][0], k2 = h ? C2[i][1] : C2[i][0];
-        const float b1 = __shfl_xor(h ? M1[i][0] : M1[i][1], 32, 64), b2 = __shfl_xor(h ? M2[i][0] : M2[i][1], 32, 64),
-                    b3 = __shfl_xor(h ? M3[i][0] : M3[i][1], 32, 64);
-        const int j1 = __shfl_xor(h ? C1[i][0] : C1[i][1], 32, 64), j2 = __shfl_xor(h ? C2[i][0] : C2[i][1], 32, 64);
+        float a1 = h ? st.M1[i][1] : st.M1[i][0], a2 = h ? st.M2[i][1] : st.M2[i][0], a3 = h ? st.M3[i][1] : st.M3[i][0];
+        int k1 = h ? st.C1[i][1] : st.C1[i][0], k2 = h ? st.C2[i][1] : st.C2[i][0];
+        const float b1 = __shfl_xor(h ? st.M1[i][0] : st.M1[i][1], 32, 64), b2 = __shfl_xor(h ? st.M2[i][0] : st.M2[i][1], 32, 64),
+                    b3 = __shfl_xor(h ? st.M3[i][0] : st.M3[i][1], 32, 64);
+        const int j1 = __shfl_xor(h ? st.C1[i][0] : st.C1[i][1], 32, 64), j2 = __shfl_xor(h ? st.C2[i][0] : st.C2[i][1], 32, 64);
         nnf_insert3(b1, j1, a1, a2, a3, k1, k2);
         nnf_insert3(b2, j2, a1, a2, a3, k1, k2);
         nnf_insert3(b3, -1, a1, a2, a3, k1, k2);       // only its value can matter (as m3)
         m1[i] = a1 * inv_S; m2[i] = a2 * inv_S; m3[i] = a3 * inv_S; c1[i] = k1; c2[i] = k2;
     }
+}
+
+// One call over the whole cloud (every query tile active).
+template <int NQ, bool IMAGE>
+__device__ __forceinline__ void nnf_scan_mfma_core(const float* __restrict__ s, int n_chunks, const NnfScales& k, const float (&qx)[NQ],
+                                                   const float (&qy)[NQ], const float (&qz)[NQ], float (&m1)[NQ], float (&m2)[NQ],
+                                                   float (&m3)[NQ], int (&c1)[NQ], int (&c2)[NQ]) {
+    NnfMfmaState<NQ> st;
+    nnf_mfma_begin<NQ>(st, k, qx, qy, qz);
+    nnf_mfma_tiles<NQ, IMAGE, false>(st, s, n_chunks, 0, (n_chunks + 1) >> 1, 0, k, ~0u);
+    nnf_mfma_end<NQ>(st, k, m1, m2, m3, c1, c2);
 }
 
 // Stand-alone form: scales from this wave's own queries, A operands built on the fly.
@@ -394,7 +433,8 @@ __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_c
         const float thr = m1[i] + (2.f * E + 1.0e-6f * (fmaxf(m1[i] + qq, 0.f) + E));
         // a tile whose best possible distance cannot beat the exact minimum carried in from earlier tiles is skipped:
         // D(p) >= t(p) - E + |q - c|^2 (1 - 3u) for every point of this tile, and its fp32 distance is >= D (1 - 6u)
-        const bool live = !(m1[i] - E + qq * 0.998f > best[i] * 1.000001f);
+        // (m1 = +INF: this query was not scanned at all -- a padding query of a skipped query tile -- nothing to resolve)
+        const bool live = m1[i] < INFINITY && !(m1[i] - E + qq * 0.998f > best[i] * 1.000001f);
         const bool fast = live && m3[i] > thr;
         if (fast) {
             // the exact winner is in chunk c1 or c2: lower chunk first so that ties keep the lowest index

@@ -48,3 +48,95 @@ extern "C" int saga_vertex_normals_subset(const saga_model_t* m, const float* ve
     SAGA_CHECK_ARG(sel || n_sel == 0, "saga_vertex_normals_subset: null selection");
     return launch(m, verts, sel, n_sel, normals, B, stream);
 }
+
+// ---- the loss kernel's reads of the mesh, served once per candidate from LDS (saga_fit_step) --------------------------------
+// One block per candidate stages the "ring" -- every corner of a face that touches a right-hand vertex (tables' ring_ids: 6,485
+// vertices = 78 KB on the synthetic mesh with random faces, two blocks per CU; ~1 k on a real mesh) -- in LDS with one gather in
+// ascending id order, computes the right-hand vertex normals from there (same sums as saga_vertex_normal, face by face in ascending
+// order: same bits) and writes the vertices the loss reads (markers / hand / feet: tables' unique ids) as compact rows.  The loss
+// kernel then touches neither the mesh nor its faces: its ~14k scattered 12-B corner reads per candidate were 2 GB of L2-missing
+// traffic per launch and a fifth of its time (three blocks per CU each waiting on them).  The index chain of the normals (range
+// of incident faces -> packed corner ids; model constants) is fetched BEFORE the gather, so the block waits for memory only twice.
+#define RING_THREADS 512
+#define RING_NF 12              // faces per hand vertex whose packed corner ids are fetched up front
+#define RING_MAXH 2             // hand vertices per lane (n_hand <= 1,024)
+__global__ __launch_bounds__(RING_THREADS) void hand_ring_kernel(saga_grasp_tables_t tb, const float* __restrict__ verts,
+                                                                 float* __restrict__ uniq_rows, float* __restrict__ hand_normals, int V) {
+    extern __shared__ __attribute__((aligned(16))) float ring_smem[];        // [n_ring*3]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* vb = verts + (size_t)b * V * 3;
+    const int H = tb.n_hand;
+    int e0[RING_MAXH], e1[RING_MAXH];
+    int2 tri[RING_MAXH][RING_NF];
+#pragma unroll
+    for (int r = 0; r < RING_MAXH; ++r) {
+        const int i = tid + r * RING_THREADS;
+        e0[r] = i < H ? tb.hand_tri_ptr[i] : 0;
+        e1[r] = i < H ? tb.hand_tri_ptr[i + 1] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < RING_MAXH; ++r)
+#pragma unroll
+        for (int u = 0; u < RING_NF; ++u) tri[r][u] = reinterpret_cast<const int2*>(tb.hand_tri)[max(min(e0[r] + u, e1[r] - 1), 0)];
+    typedef float f32x3_t __attribute__((ext_vector_type(3)));
+    // ring gather, eight vertices per lane in flight
+    for (int i0 = 0; i0 < tb.n_ring; i0 += RING_THREADS * 8) {
+        f32x3_t p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + u * RING_THREADS + tid, tb.n_ring - 1);
+            p[u] = *reinterpret_cast<const f32x3_t*>(vb + (size_t)tb.ring_ids[i] * 3);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * RING_THREADS + tid;
+            if (i < tb.n_ring) { ring_smem[i * 3] = p[u].x; ring_smem[i * 3 + 1] = p[u].y; ring_smem[i * 3 + 2] = p[u].z; }
+        }
+    }
+    // compact rows of the loss vertices
+    float* urow = uniq_rows + (size_t)b * tb.n_unique * 3;
+    for (int i = tid; i < tb.n_unique; i += RING_THREADS) {
+        const f32x3_t p = *reinterpret_cast<const f32x3_t*>(vb + (size_t)tb.unique_ids[i] * 3);
+        urow[i * 3] = p.x; urow[i * 3 + 1] = p.y; urow[i * 3 + 2] = p.z;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RING_MAXH; ++r) {
+        const int i = tid + r * RING_THREADS;
+        if (i >= H) continue;
+        float n[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < RING_NF; ++u)
+            if (e0[r] + u < e1[r]) saga_face_normal_add(ring_smem, tri[r][u].x & 0xffff, (unsigned)tri[r][u].x >> 16, tri[r][u].y, n);
+        for (int e = e0[r] + RING_NF; e < e1[r]; e += 8) {       // valence beyond RING_NF (rare): eight more per round trip
+            int2 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = reinterpret_cast<const int2*>(tb.hand_tri)[min(e + u, e1[r] - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e + u < e1[r]) saga_face_normal_add(ring_smem, t[u].x & 0xffff, (unsigned)t[u].x >> 16, t[u].y, n);
+        }
+        saga_normal_finish(n);
+        float* d = hand_normals + ((size_t)b * H + i) * 3;
+        d[0] = n[0]; d[1] = n[1]; d[2] = n[2];
+    }
+}
+
+// returns 1 (nothing launched) when the tables carry no ring or it does not fit the LDS of a CU
+int saga_launch_hand_ring(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* verts, float* uniq_rows,
+                          float* hand_normals, int B, void* stream) {
+    if (!tb->ring_ids || !tb->hand_tri_ptr || !tb->hand_tri || tb->n_ring <= 0 || tb->n_hand > RING_MAXH * RING_THREADS) return 1;
+    const size_t lds = (size_t)tb->n_ring * 3 * sizeof(float);
+    if (lds > 160 * 1024) return 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SAGA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hand_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+        attr_set = true;
+    }
+    void* prof = saga_prof_begin(SAGA_PROF_NORMALS, stream);
+    hand_ring_kernel<<<B, RING_THREADS, lds, (hipStream_t)stream>>>(*tb, verts, uniq_rows, hand_normals, m->V);
+    saga_prof_end(prof);
+    SAGA_LAUNCH_CHECK();
+    return 0;
+}

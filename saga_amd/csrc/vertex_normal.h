@@ -41,6 +41,28 @@ __device__ __forceinline__ void saga_vertex_normal(const float* __restrict__ vb,
     ox = nx; oy = ny; oz = nz;
 }
 
+// The same sums in pieces, for a caller that holds the mesh (or the part of it the faces touch) in a flat [n,3] array such as LDS
+// and walks the incident faces itself, in ascending order: same arithmetic -> same bits as saga_vertex_normal.
+__device__ __forceinline__ void saga_face_normal_add(const float* __restrict__ sv, int i0, int i1, int i2, float (&n)[3]) {
+#pragma clang fp contract(off)
+    const float* p0 = sv + i0 * 3;
+    const float* p1 = sv + i1 * 3;
+    const float* p2 = sv + i2 * 3;
+    const float ax = p1[0] - p0[0], ay = p1[1] - p0[1], az = p1[2] - p0[2];
+    const float bx = p2[0] - p0[0], by = p2[1] - p0[1], bz = p2[2] - p0[2];
+    n[0] += ay * bz - az * by;
+    n[1] += az * bx - ax * bz;
+    n[2] += ax * by - ay * bx;
+}
+__device__ __forceinline__ void saga_normal_finish(float (&n)[3]) {
+#pragma clang fp contract(off)
+    float nx = n[0], ny = n[1], nz = n[2];
+    const float sq = nx * nx + ny * ny + nz * nz;
+    if (sq > 0.f) { const float inv = 1.0f / sqrtf(sq); nx *= inv; ny *= inv; nz *= inv; }
+    if (isnan(nx)) { nx = 0.f; ny = 0.f; nz = 1.f; }
+    n[0] = nx; n[1] = ny; n[2] = nz;
+}
+
 // NV vertices per lane at once (ids v[k], k < NV; v[k] < 0 = none): the same sums in the same order as saga_vertex_normal, but the
 // NV chains of dependent reads (incidence range -> face ids -> corner coordinates) advance together, two faces per vertex and
 // step, so a lane waits for 1/NV as many memory round trips.

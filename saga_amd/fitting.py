@@ -344,8 +344,13 @@ class FittingOP:
     def __del__(self):
         self.close()
 
+    def _tstruct(self):
+        """The loss tables with the mesh-dependent part (the hand's face ring) of the current body model: lets ``saga_fit_step``
+        write the vertices the loss reads as compact rows in its skinning kernel and take the hand normals from LDS."""
+        return self.tables.struct_for_mesh(self.bm.faces, self.bm.num_verts)
+
     def _workspace(self, n_obj):
-        n = _lib.load().saga_fit_workspace_floats(self.bm.handle(self.device), ctypes.byref(self.tables.struct), self.batch_size, n_obj)
+        n = _lib.load().saga_fit_workspace_floats(self.bm.handle(self.device), ctypes.byref(self._tstruct()), self.batch_size, n_obj)
         if self._ws is None or self._ws.numel() < n:
             self._ws = torch.zeros(n, device=self.device, dtype=torch.float32)      # contract: zero-initialised
         return self._ws
@@ -398,7 +403,8 @@ class FittingOP:
                       P(self.vars), P(o['m']), P(o['v']), P(ws), P(problem['loss']), P(loss_terms), P(problem['markers_rec']),
                       self.batch_size)
             return problem['loss'], problem['markers_rec']
-        rest = (self._native_handles(), ctypes.byref(self.tables.struct), ctypes.byref(problem['struct']),
+        tstruct = self._tstruct()
+        rest = (self._native_handles(), ctypes.byref(tstruct), ctypes.byref(problem['struct']),
                 ctypes.byref(cfg), P(self.vars), P(o['m']), P(o['v']), P(self._workspace(problem['struct'].n_obj)), P(problem['loss']),
                 P(loss_terms), P(problem['markers_rec']), self.batch_size)
         if self.sparse_backward:
@@ -413,7 +419,7 @@ class FittingOP:
 
     def workspace_view(self, name, n_obj, shape, dtype=torch.float32):
         """Intermediate of the last ``native_step`` by name (``saga_fit_workspace_offset``), e.g. ``'vertices'``."""
-        off = _lib.load().saga_fit_workspace_offset(self.bm.handle(self.device), ctypes.byref(self.tables.struct),
+        off = _lib.load().saga_fit_workspace_offset(self.bm.handle(self.device), ctypes.byref(self._tstruct()),
                                                     self.batch_size, n_obj, name.encode())
         if off < 0:
             raise KeyError(name)
@@ -426,7 +432,7 @@ class FittingOP:
         packed = self.vars if packed is None else packed
         B = packed.shape[0]
         out = torch.empty(B, _lib.BODY_PARAM_COUNT, device=self.device)
-        n = _lib.load().saga_fit_workspace_floats(self.bm.handle(self.device), ctypes.byref(self.tables.struct), B, 1)
+        n = _lib.load().saga_fit_workspace_floats(self.bm.handle(self.device), ctypes.byref(self._tstruct()), B, 1)
         ws = self._ws if (self._ws is not None and self._ws.numel() >= n) else torch.empty(n, device=self.device)
         _lib.call('saga_fit_decode', self.device, self._native_handles(), _lib.ptr(packed), _lib.ptr(out), _lib.ptr(ws), B)
         return {k: out[:, a:b].clone() for k, (a, b) in _lib.BODY_PARAM_SLICES.items()}

@@ -32,12 +32,60 @@ class GraspTables:
         self.n_markers, self.n_hand, self.n_foot, self.n_unique = len(markers), len(hand), len(foot), len(uniq)
         self.max_id = int(uniq.max())
         p = lambda t: ctypes.c_void_p(t.data_ptr())
-        self.struct = _lib.GraspTables(
+        self._fields = dict(
             n_markers=self.n_markers, n_hand=self.n_hand, n_foot=self.n_foot,
             n_body_markers=min(n_body_markers, self.n_markers), n_unique=self.n_unique,
             marker_ids=p(self.marker_ids), hand_ids=p(self.hand_ids), foot_ids=p(self.foot_ids),
             hand_weights=p(self.hand_weights), unique_ids=p(self.unique_ids), marker_slot=p(self.marker_slot),
             hand_slot=p(self.hand_slot), foot_slot=p(self.foot_slot))
+        self.struct = _lib.GraspTables(**self._fields)
+        self._hand_host, self._uniq_host, self._device = hand, uniq, device
+        self._mesh_structs = {}
+
+    def struct_for_mesh(self, faces, n_verts):
+        """The table struct with the optional mesh-dependent fields filled in (``include/saga_hip.h``: ``ring_ids``,
+        ``hand_tri_ptr``, ``hand_tri``) for a mesh with these ``faces`` [F,3]: what lets ``saga_fit_step`` stage
+        the hand's face ring in LDS and take the hand normals from there.  Built once per mesh (cached by the identity of ``faces``)."""
+        key = (id(faces), int(n_verts))
+        hit = self._mesh_structs.get(key)
+        if hit is not None:
+            return hit[0]
+        faces = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+        V = int(n_verts)
+        is_hand = np.zeros(V, dtype=bool)
+        is_hand[self._hand_host] = True
+        touching = is_hand[faces].any(axis=1)
+        ring = np.unique(faces[touching].reshape(-1)) if touching.any() else np.zeros(0, dtype=np.int64)
+        ring_slot = np.full(V, -1, dtype=np.int32)
+        ring_slot[ring] = np.arange(ring.size, dtype=np.int32)
+        # incident faces of every hand vertex in ascending face order (the order saga_vertex_normal sums in)
+        fid = np.nonzero(touching)[0]
+        ptr = np.zeros(self.n_hand + 1, dtype=np.int32)
+        rows = []
+        inc = {}
+        for f in fid:
+            for v in faces[f]:
+                if is_hand[v]:
+                    inc.setdefault(int(v), []).append(int(f))
+        for i, v in enumerate(self._hand_host):
+            fl = sorted(inc.get(int(v), []))      # one entry per incidence (corner), like the model's vertex -> face CSR
+            ptr[i + 1] = ptr[i] + len(fl)
+            rows.extend(fl)
+        tri = np.zeros((max(len(rows), 1), 2), dtype=np.int64)
+        if rows:
+            c = ring_slot[faces[np.asarray(rows)]].astype(np.int64)
+            tri[:len(rows), 0] = c[:, 0] | (c[:, 1] << 16)
+            tri[:len(rows), 1] = c[:, 2]
+        tri = tri.astype(np.uint32).view(np.int32)
+        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=self._device)
+        if ring.size >= 65536:
+            raise ValueError('the hand ring has %d vertices: too many for the packed corner table' % ring.size)
+        keep = [i32(ring), i32(ptr), i32(tri)]
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        st = _lib.GraspTables(**dict(self._fields, n_ring=int(ring.size), ring_ids=p(keep[0]),
+                                     hand_tri_ptr=p(keep[1]), hand_tri=p(keep[2])))
+        self._mesh_structs[key] = (st, keep, faces)
+        return st
 
 
 class _GraspLossFn(torch.autograd.Function):

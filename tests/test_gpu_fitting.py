@@ -275,6 +275,42 @@ def test_ops_follow_the_tensors_device_not_the_current_device(body_model_dir):
     assert rc == -1 and b'current device' in _lib.load().saga_last_error()
 
 
+@pytest.mark.parametrize('sparse', [False, True])
+def test_fused_skinning_loss_inputs_equal_the_standalone_kernels(body_model_dir, sparse):
+    """saga_fit_step runs the skinning one block per candidate with the mesh in LDS and serves the loss kernel's reads of it
+    from there (hand vertices, markers, foot heights, hand normals: skin_fwd_cand_kernel + grasp_loss_fwd_fast_kernel<PRE>).
+    SAGA_FIT_NO_PRE=1 runs the two stand-alone kernels instead.  Everything must be equal bit for bit: vertices, normals,
+    every loss term, the variables after the update."""
+    import os
+    B, O = 6, 2048
+    outs = []
+    for no_pre in (False, True):
+        op, vp, idx, var_np, d = _setup(body_model_dir, B)
+        op.sparse_backward = sparse
+        op.bm = op.bm_male
+        op.set_variables(var_np)
+        cu = lambda a: torch.from_numpy(a).cuda()
+        prob = op.make_problem(cu(d['markers']), cu(d['verts_o']), cu(d['normals_o']), cu(d['oc']), cu(d['mc']))
+        terms = torch.zeros(B, 16, device='cuda')
+        if no_pre:
+            os.environ['SAGA_FIT_NO_PRE'] = '1'
+        try:
+            for _ in range(3):
+                loss, mk = op.native_step(2, prob, terms)
+        finally:
+            os.environ.pop('SAGA_FIT_NO_PRE', None)
+        H = op.tables.n_hand
+        outs.append([loss.clone(), mk.clone(), terms.clone(), op.vars.clone(),
+                     op.workspace_view('vertices', O, (B, op.bm.num_verts, 3)).clone(),
+                     op.workspace_view('hand_normals', O, (B, H, 3)).clone(), op.workspace_view('hand_rec', O, (B, H, 3)).clone(),
+                     op.workspace_view('h2o_signed', O, (B, H)).clone(), op.workspace_view('o2h_signed', O, (B, O)).clone(),
+                     op.workspace_view('idx_o2h', O, (B, O), torch.int32).clone()])
+    names = ['loss', 'markers', 'terms', 'vars', 'vertices', 'hand_normals', 'hand_rec', 'h2o', 'o2h', 'idx_o2h']
+    for a, b_, n in zip(outs[0], outs[1], names):
+        assert torch.equal(a, b_), n
+    assert torch.isfinite(outs[0][0]).all() and outs[0][5].abs().sum() > 0
+
+
 def test_loss_vertices_only_variant_equals_full_mesh(body_model_dir):
     """`loss_vertices_only=True` builds the body model for the ~1,100 vertices the loss reads (saga_model_create_subset).
     The kept vertices are bit-identical to the full mesh's, so the first iteration's loss terms, counts and fitted markers
