@@ -163,6 +163,22 @@ int saga_chamfer_bwd(const float* x, const float* y, const int32_t* idx1, const 
                      const float* g_dist1, const float* g_dist2, float* g_x, float* g_y,
                      int N, int P1, int P2, void* stream);
 
+/* point2point_signed(x, y, x_normals, y_normals) of utils/train_helper.py:17-86 as one operator (call sites
+ * WholeGraspPose/models/fittingop.py:183-184, MotionFill/models/fittingop.py:154-157, WholeGraspPose/trainer.py:280-281):
+ * the nearest-neighbour search above, then x2y = x - y[xidx], y2x = y - x[yidx], their norms, and the sign of the dot product
+ * with the OTHER cloud's normal at the neighbour (a NULL normal array leaves that direction unsigned; sign(0) = 0).
+ *   y2x_signed [N,P2], x2y_signed [N,P1], yidx [N,P2], xidx [N,P1] int32; y2x_vec [N,P2,3] / x2y_vec [N,P1,3] optional (NULL).
+ * Backward: gradients of the signed distances and / or of the difference vectors (each may be NULL) -> g_x [N,P1,3], g_y
+ * [N,P2,3] (written; either may be NULL).  The reference's gather backward is a scatter-add with float atomics; here it is a
+ * fixed-order gather: bit-reproducible.  A point that coincides with its neighbour gets no distance gradient (torch: NaN). */
+int saga_p2p_signed_fwd(const float* x, const float* y, const float* x_normals, const float* y_normals,
+                        float* y2x_signed, float* x2y_signed, int32_t* yidx, int32_t* xidx, float* y2x_vec, float* x2y_vec,
+                        int N, int P1, int P2, void* stream);
+int saga_p2p_signed_bwd(const float* x, const float* y, const int32_t* yidx, const int32_t* xidx,
+                        const float* y2x_signed, const float* x2y_signed,
+                        const float* g_y2x_signed, const float* g_x2y_signed, const float* g_y2x_vec, const float* g_x2y_vec,
+                        float* g_x, float* g_y, int N, int P1, int P2, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Vertex normals.  Replaces Open3D TriangleMesh.compute_vertex_normals()
  * (WholeGraspPose/models/fittingop.py:158-164): area-weighted sum of face normals, normalised.

@@ -227,3 +227,138 @@ extern "C" int saga_chamfer_bwd(const float* x, const float* y, const int32_t* i
     SAGA_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- point2point_signed (utils/train_helper.py:17-86) as ONE operator ------------------------------------------------------
+// Forward: the bidirectional nearest-neighbour search above, then per point the difference vector to its neighbour, its norm
+// and the sign of its dot product with the OTHER cloud's normal at the neighbour (:65-81; no normals given: unsigned).
+// Same operation order as the reference's torch code: norm = sqrt((dx dx + dy dy) + dz dz), dot = (nx dx + ny dy) + nz dz.
+__global__ void p2p_signed_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ b_normals,
+                                  const int32_t* __restrict__ idx, float* __restrict__ signed_dist, float* __restrict__ vec, int N, int Pa,
+                                  int Pb) {
+#pragma clang fp contract(off)
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * Pa) return;
+    const int n = (int)(i / Pa);
+    const size_t k = (size_t)n * Pb + idx[i];
+    const float dx = a[i * 3] - b[k * 3], dy = a[i * 3 + 1] - b[k * 3 + 1], dz = a[i * 3 + 2] - b[k * 3 + 2];
+    float d = sqrtf((dx * dx + dy * dy) + dz * dz);
+    if (b_normals) {
+        const float dot = (b_normals[k * 3] * dx + b_normals[k * 3 + 1] * dy) + b_normals[k * 3 + 2] * dz;
+        d *= (dot > 0.f) ? 1.f : ((dot < 0.f) ? -1.f : 0.f);
+    }
+    signed_dist[i] = d;
+    if (vec) { vec[i * 3] = dx; vec[i * 3 + 1] = dy; vec[i * 3 + 2] = dz; }
+}
+
+extern "C" int saga_p2p_signed_fwd(const float* x, const float* y, const float* x_normals, const float* y_normals, float* y2x_signed,
+                                   float* x2y_signed, int32_t* yidx, int32_t* xidx, float* y2x_vec, float* x2y_vec, int N, int P1, int P2,
+                                   void* stream) {
+    SAGA_CHECK_ARG(N >= 0 && P1 >= 0 && P2 >= 0, "saga_p2p_signed_fwd: negative size");
+    if (N == 0 || (P1 == 0 && P2 == 0)) return 0;
+    SAGA_CHECK_ARG(P1 > 0 && P2 > 0, "saga_p2p_signed_fwd: empty cloud (P1=%d, P2=%d) has no nearest neighbour", P1, P2);
+    SAGA_CHECK_ARG(x && y && y2x_signed && x2y_signed && yidx && xidx, "saga_p2p_signed_fwd: null argument");
+    SAGA_CHECK_ARG(N <= 65535, "saga_p2p_signed_fwd: batch %d exceeds 65535", N);
+    hipStream_t st = (hipStream_t)stream;
+    void* prof = saga_prof_begin(SAGA_PROF_CHAMFER, stream);
+    int rc = launch_scan(x, y, nullptr, xidx, N, P1, P2, st);
+    if (!rc) rc = launch_scan(y, x, nullptr, yidx, N, P2, P1, st);
+    saga_prof_end(prof);
+    if (rc) return rc;
+    // x2y = x - y[xidx], signed by y_normals[xidx] (:76-81); y2x = y - x[yidx], signed by x_normals[yidx] (:68-74)
+    p2p_signed_kernel<<<(unsigned)(((size_t)N * P1 + 255) / 256), 256, 0, st>>>(x, y, y_normals, xidx, x2y_signed, x2y_vec, N, P1, P2);
+    SAGA_LAUNCH_CHECK();
+    p2p_signed_kernel<<<(unsigned)(((size_t)N * P2 + 255) / 256), 256, 0, st>>>(y, x, x_normals, yidx, y2x_signed, y2x_vec, N, P2, P1);
+    SAGA_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward.  A point p of cloud a receives (i) its own term -- d|a_p - b_k| = sign^2-free: g * sign * unit(a_p - b_k), plus the
+// gradient of its difference vector -- and (ii) minus the same quantities of every point q of b whose neighbour is p (the
+// reference's gather backward is a scatter-add, :59-63).  Like saga_chamfer_bwd this is a GATHER in a fixed order (own term,
+// then ascending q; the other cloud's neighbour indices stream through LDS): no atomics, bit-reproducible, batch-independent.
+// sign comes from the forward's signed distance (its sign IS the sign factor; 0 -> no gradient, like torch.sign).
+__global__ __launch_bounds__(NG_THREADS) void p2p_grad_gather_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                     const int32_t* __restrict__ idx_ab, const float* __restrict__ sd_a,
+                                                                     const float* __restrict__ g_sd_a, const float* __restrict__ g_vec_a,
+                                                                     const int32_t* __restrict__ idx_ba, const float* __restrict__ sd_b,
+                                                                     const float* __restrict__ g_sd_b, const float* __restrict__ g_vec_b,
+                                                                     float* __restrict__ g_a, int Pa, int Pb) {
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) int32_t sidx[NG_TILE];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int p = blockIdx.x * NG_THREADS + tid;
+    const bool live = p < Pa;
+    const float* an = a + (size_t)n * Pa * 3;
+    const float* bn = b + (size_t)n * Pb * 3;
+    auto sgn = [](float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); };
+    float ax = 0.f, ay = 0.f, az = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+    if (live) {
+        const size_t i = (size_t)n * Pa + p;
+        ax = an[p * 3]; ay = an[p * 3 + 1]; az = an[p * 3 + 2];
+        if (g_sd_a) {
+            const int k = idx_ab[i];
+            const float dx = ax - bn[k * 3], dy = ay - bn[k * 3 + 1], dz = az - bn[k * 3 + 2];
+            const float nrm = sqrtf((dx * dx + dy * dy) + dz * dz);
+            const float c = nrm > 0.f ? g_sd_a[i] * sgn(sd_a[i]) / nrm : 0.f;
+            sx = c * dx; sy = c * dy; sz = c * dz;
+        }
+        if (g_vec_a) { sx += g_vec_a[i * 3]; sy += g_vec_a[i * 3 + 1]; sz += g_vec_a[i * 3 + 2]; }
+    }
+    if (g_sd_b || g_vec_b) {
+        const int32_t* ib = idx_ba + (size_t)n * Pb;
+        const int me = live ? p : -2;
+        for (int t0 = 0; t0 < Pb; t0 += NG_TILE) {
+            const int cnt = min(NG_TILE, Pb - t0);
+            if (t0) __syncthreads();
+            for (int i = tid; i < NG_TILE; i += NG_THREADS) sidx[i] = i < cnt ? ib[t0 + i] : -1;
+            __syncthreads();
+            const int cnt4 = (cnt + 3) & ~3;
+            for (int j = 0; j < cnt4; j += 4) {
+                const int4 v = *reinterpret_cast<const int4*>(sidx + j);
+                if (v.x == me || v.y == me || v.z == me || v.w == me) {
+                    const int vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4)
+                        if (vv[c4] == me) {
+                            const int q = t0 + j + c4;
+                            const size_t qi = (size_t)n * Pb + q;
+                            if (g_sd_b) {
+                                const float dx = bn[q * 3] - ax, dy = bn[q * 3 + 1] - ay, dz = bn[q * 3 + 2] - az;
+                                const float nrm = sqrtf((dx * dx + dy * dy) + dz * dz);
+                                const float c = nrm > 0.f ? g_sd_b[qi] * sgn(sd_b[qi]) / nrm : 0.f;
+                                sx -= c * dx; sy -= c * dy; sz -= c * dz;
+                            }
+                            if (g_vec_b) { sx -= g_vec_b[qi * 3]; sy -= g_vec_b[qi * 3 + 1]; sz -= g_vec_b[qi * 3 + 2]; }
+                        }
+                }
+            }
+        }
+    }
+    if (live) {
+        float* o = g_a + ((size_t)n * Pa + p) * 3;
+        o[0] = sx; o[1] = sy; o[2] = sz;
+    }
+}
+
+extern "C" int saga_p2p_signed_bwd(const float* x, const float* y, const int32_t* yidx, const int32_t* xidx, const float* y2x_signed,
+                                   const float* x2y_signed, const float* g_y2x_signed, const float* g_x2y_signed,
+                                   const float* g_y2x_vec, const float* g_x2y_vec, float* g_x, float* g_y, int N, int P1, int P2,
+                                   void* stream) {
+    SAGA_CHECK_ARG(N >= 0 && P1 >= 0 && P2 >= 0, "saga_p2p_signed_bwd: negative size");
+    if (N == 0 || P1 == 0 || P2 == 0) return 0;
+    SAGA_CHECK_ARG(x && y && yidx && xidx && y2x_signed && x2y_signed, "saga_p2p_signed_bwd: null argument");
+    SAGA_CHECK_ARG(g_x || g_y, "saga_p2p_signed_bwd: no gradient requested");
+    SAGA_CHECK_ARG(N <= 65535, "saga_p2p_signed_bwd: batch %d exceeds 65535", N);
+    hipStream_t st = (hipStream_t)stream;
+    if (g_x) {
+        p2p_grad_gather_kernel<<<dim3((P1 + NG_THREADS - 1) / NG_THREADS, N), NG_THREADS, 0, st>>>(
+            x, y, xidx, x2y_signed, g_x2y_signed, g_x2y_vec, yidx, y2x_signed, g_y2x_signed, g_y2x_vec, g_x, P1, P2);
+        SAGA_LAUNCH_CHECK();
+    }
+    if (g_y) {
+        p2p_grad_gather_kernel<<<dim3((P2 + NG_THREADS - 1) / NG_THREADS, N), NG_THREADS, 0, st>>>(
+            y, x, yidx, y2x_signed, g_y2x_signed, g_y2x_vec, xidx, x2y_signed, g_x2y_signed, g_x2y_vec, g_y, P2, P1);
+        SAGA_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -231,6 +231,49 @@ def test_point2point_signed_against_reference_golden(golden, name):
     np.testing.assert_allclose(x.grad.cpu().numpy(), g[f'{name}_grad_x'], rtol=1e-4, atol=1e-5)
 
 
+def test_p2p_signed_operator_against_oracle_with_vectors_and_both_gradients():
+    """saga_p2p_signed_fwd/bwd (one HIP operator) against the pinned oracle (oracle/geometry_ref.point2point_signed, itself checked
+    against the reference function's outputs): signed distances, difference vectors, indices, and the gradients w.r.t. BOTH clouds
+    of a loss that uses all four float outputs (the MotionFill consumer reads the vectors, fittingop.py:154).  Many object points
+    share one hand vertex (3,001 points against 97), the index tiles are ragged; the backward is bit-reproducible run to run."""
+    from saga_amd.geometry import point2point_signed
+    g = torch.Generator().manual_seed(21)
+    N, P1, P2 = 3, 97, 3001
+    x = torch.randn(N, P1, 3, generator=g) * 0.1
+    y = torch.randn(N, P2, 3, generator=g) * 0.1
+    xn = torch.nn.functional.normalize(torch.randn(N, P1, 3, generator=g), dim=-1)
+    yn = torch.nn.functional.normalize(torch.randn(N, P2, 3, generator=g), dim=-1)
+    w = [torch.randn(s, generator=g) for s in ((N, P2), (N, P1), (N, P2, 3), (N, P1, 3))]
+
+    def run(device, dtype, fn, normals=True):
+        xr = x.to(device, dtype).requires_grad_(True)
+        yr = y.to(device, dtype).requires_grad_(True)
+        out = fn(xr, yr, xn.to(device, dtype) if normals else None, yn.to(device, dtype) if normals else None, return_vector=True)
+        loss = sum((o * wi.to(device, dtype)).sum() for o, wi in zip((out[0], out[1], out[4], out[5]), w))
+        loss.backward()
+        return [o.detach().cpu() for o in out], xr.grad.cpu(), yr.grad.cpu()
+
+    for normals in (True, False):
+        out_h, gx_h, gy_h = run('cuda', torch.float32, point2point_signed, normals)
+        out_r, gx_r, gy_r = run('cpu', torch.float64, geometry_ref.point2point_signed, normals)
+        # the oracle's float64 search can pick another index at a float32 near-tie: compare where the indices agree (all, here)
+        assert_same(out_h[2].numpy(), out_r[2].numpy(), 'yidx')
+        assert_same(out_h[3].numpy(), out_r[3].numpy(), 'xidx')
+        for k in (0, 1, 4, 5):
+            np.testing.assert_allclose(out_h[k].numpy(), out_r[k].numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(gx_h.numpy(), gx_r.numpy(), rtol=1e-4, atol=1e-4)       # ~31 scattered terms per x point
+        np.testing.assert_allclose(gy_h.numpy(), gy_r.numpy(), rtol=1e-4, atol=1e-5)
+        if not normals:
+            assert (out_h[0] >= 0).all() and (out_h[1] >= 0).all()
+        out_2, gx_2, gy_2 = run('cuda', torch.float32, point2point_signed, normals)
+        assert torch.equal(gx_2, gx_h) and torch.equal(gy_2, gy_h)
+    # only x needs a gradient (the SAGA call sites): y's gradient is not computed
+    xr = x.cuda().requires_grad_(True)
+    o = point2point_signed(xr, y.cuda(), xn.cuda(), yn.cuda())
+    (o[0].sum() + o[1].sum()).backward()
+    assert xr.grad is not None and len(o) == 4 and o[2].dtype == torch.int32
+
+
 def test_point2point_signed_value_error():
     from saga_amd.geometry import point2point_signed
     with pytest.raises(ValueError):
