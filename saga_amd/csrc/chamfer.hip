@@ -340,6 +340,108 @@ __global__ __launch_bounds__(NG_THREADS) void p2p_grad_gather_kernel(const float
     }
 }
 
+// The same backward for small target clouds (Pa <= P2P_FX_MAX: every call SAGA makes -- 143 markers / 778 hand vertices against
+// 2,048 object points), O(Pa + Pb) per batch element instead of the gather's O(Pa Pb) compares: one block per batch element
+// scatter-adds the other cloud's terms into 64-bit FIXED-POINT accumulators in LDS.  Integer adds are associative, so the result
+// does not depend on the order the LDS atomics land in (bit-reproducible, batch-independent), and it is the exactly rounded sum:
+// the grid is 2^-k with k chosen per batch element from the largest term M so that M Pb 2^k < 2^62 -- every term is on the grid to
+// within 2^-49 M, far below float32 rounding.  (Float atomics, the CUDA reference's way, make the sum order-dependent.)
+#define P2P_FX_MAX 2048
+#define P2P_FX_THREADS 256
+__global__ __launch_bounds__(P2P_FX_THREADS) void p2p_grad_fixed_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                        const int32_t* __restrict__ idx_ab, const float* __restrict__ sd_a,
+                                                                        const float* __restrict__ g_sd_a, const float* __restrict__ g_vec_a,
+                                                                        const int32_t* __restrict__ idx_ba, const float* __restrict__ sd_b,
+                                                                        const float* __restrict__ g_sd_b, const float* __restrict__ g_vec_b,
+                                                                        float* __restrict__ g_a, int Pa, int Pb) {
+#pragma clang fp contract(off)
+    __shared__ unsigned long long acc[P2P_FX_MAX * 3];
+    __shared__ float smax[P2P_FX_THREADS / 64];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float* an = a + (size_t)n * Pa * 3;
+    const float* bn = b + (size_t)n * Pb * 3;
+    auto sgn = [](float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); };
+    for (int i = tid; i < Pa * 3; i += P2P_FX_THREADS) acc[i] = 0ull;
+    // the term point q of b sends to its neighbour in a (evaluated twice: once for the scale, once to add -- cheaper than storing it)
+    auto term = [&](int q, float& tx, float& ty, float& tz, int& p) {
+        const size_t qi = (size_t)n * Pb + q;
+        p = idx_ba[qi];
+        tx = 0.f; ty = 0.f; tz = 0.f;
+        if (g_sd_b) {
+            const float dx = bn[q * 3] - an[p * 3], dy = bn[q * 3 + 1] - an[p * 3 + 1], dz = bn[q * 3 + 2] - an[p * 3 + 2];
+            const float nrm = sqrtf((dx * dx + dy * dy) + dz * dz);
+            const float c = nrm > 0.f ? g_sd_b[qi] * sgn(sd_b[qi]) / nrm : 0.f;
+            tx = c * dx; ty = c * dy; tz = c * dz;
+        }
+        if (g_vec_b) { tx += g_vec_b[qi * 3]; ty += g_vec_b[qi * 3 + 1]; tz += g_vec_b[qi * 3 + 2]; }
+    };
+    const bool scatter = g_sd_b || g_vec_b;
+    double inv_scale = 1.0;
+    if (scatter) {
+        float m = 0.f;
+        for (int q = tid; q < Pb; q += P2P_FX_THREADS) {
+            float tx, ty, tz; int p;
+            term(q, tx, ty, tz, p);
+            const float t = fmaxf(fabsf(tx), fmaxf(fabsf(ty), fabsf(tz)));
+            m = (t <= 3.0e38f) ? fmaxf(m, t) : m;              // NaN / Inf terms do not set the scale (they poison their target below)
+        }
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((tid & 63) == 0) smax[tid >> 6] = m;
+        __syncthreads();                                        // (also: acc is zero)
+        m = smax[0];
+        for (int w = 1; w < P2P_FX_THREADS / 64; ++w) m = fmaxf(m, smax[w]);
+        int e = 0;
+        if (m > 0.f) (void)frexpf(m, &e);                      // m < 2^e
+        int lp = 1;
+        while ((1 << lp) < Pb) ++lp;                            // Pb <= 2^lp
+        const int k = max(min(61 - e - lp, 1000), -1000);
+        const double scale = ldexp(1.0, k);
+        inv_scale = ldexp(1.0, -k);
+        for (int q = tid; q < Pb; q += P2P_FX_THREADS) {
+            float tx, ty, tz; int p;
+            term(q, tx, ty, tz, p);
+            // a NaN / Inf term becomes the largest magnitude of the grid: visible in the result, never undefined behaviour
+            auto fx = [&](float v) { const double s = (double)v * scale; return (s == s && fabs(s) < 4.0e18) ? __double2ll_rn(s) : (long long)4.0e18; };
+            atomicAdd(&acc[p * 3], (unsigned long long)fx(tx));
+            atomicAdd(&acc[p * 3 + 1], (unsigned long long)fx(ty));
+            atomicAdd(&acc[p * 3 + 2], (unsigned long long)fx(tz));
+        }
+    }
+    __syncthreads();
+    for (int p = tid; p < Pa; p += P2P_FX_THREADS) {
+        const size_t i = (size_t)n * Pa + p;
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        if (g_sd_a) {
+            const int k = idx_ab[i];
+            const float dx = an[p * 3] - bn[k * 3], dy = an[p * 3 + 1] - bn[k * 3 + 1], dz = an[p * 3 + 2] - bn[k * 3 + 2];
+            const float nrm = sqrtf((dx * dx + dy * dy) + dz * dz);
+            const float c = nrm > 0.f ? g_sd_a[i] * sgn(sd_a[i]) / nrm : 0.f;
+            sx = c * dx; sy = c * dy; sz = c * dz;
+        }
+        if (g_vec_a) { sx += (double)g_vec_a[i * 3]; sy += (double)g_vec_a[i * 3 + 1]; sz += (double)g_vec_a[i * 3 + 2]; }
+        if (scatter) {
+            sx -= (double)(long long)acc[p * 3] * inv_scale;
+            sy -= (double)(long long)acc[p * 3 + 1] * inv_scale;
+            sz -= (double)(long long)acc[p * 3 + 2] * inv_scale;
+        }
+        float* o = g_a + i * 3;
+        o[0] = (float)sx; o[1] = (float)sy; o[2] = (float)sz;
+    }
+}
+
+static int p2p_grad_launch(const float* a, const float* b, const int32_t* idx_ab, const float* sd_a, const float* g_sd_a,
+                           const float* g_vec_a, const int32_t* idx_ba, const float* sd_b, const float* g_sd_b, const float* g_vec_b,
+                           float* g_a, int N, int Pa, int Pb, hipStream_t st) {
+    const bool force_gather = getenv("SAGA_P2P_GATHER") != nullptr;   // cross-check switch (read per call): the O(Pa Pb) gather
+    if (Pa <= P2P_FX_MAX && Pb <= (1 << 24) && !force_gather)
+        p2p_grad_fixed_kernel<<<N, P2P_FX_THREADS, 0, st>>>(a, b, idx_ab, sd_a, g_sd_a, g_vec_a, idx_ba, sd_b, g_sd_b, g_vec_b, g_a, Pa, Pb);
+    else
+        p2p_grad_gather_kernel<<<dim3((Pa + NG_THREADS - 1) / NG_THREADS, N), NG_THREADS, 0, st>>>(a, b, idx_ab, sd_a, g_sd_a, g_vec_a,
+                                                                                                  idx_ba, sd_b, g_sd_b, g_vec_b, g_a, Pa, Pb);
+    SAGA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int saga_p2p_signed_bwd(const float* x, const float* y, const int32_t* yidx, const int32_t* xidx, const float* y2x_signed,
                                    const float* x2y_signed, const float* g_y2x_signed, const float* g_x2y_signed,
                                    const float* g_y2x_vec, const float* g_x2y_vec, float* g_x, float* g_y, int N, int P1, int P2,
@@ -350,15 +452,12 @@ extern "C" int saga_p2p_signed_bwd(const float* x, const float* y, const int32_t
     SAGA_CHECK_ARG(g_x || g_y, "saga_p2p_signed_bwd: no gradient requested");
     SAGA_CHECK_ARG(N <= 65535, "saga_p2p_signed_bwd: batch %d exceeds 65535", N);
     hipStream_t st = (hipStream_t)stream;
-    if (g_x) {
-        p2p_grad_gather_kernel<<<dim3((P1 + NG_THREADS - 1) / NG_THREADS, N), NG_THREADS, 0, st>>>(
-            x, y, xidx, x2y_signed, g_x2y_signed, g_x2y_vec, yidx, y2x_signed, g_y2x_signed, g_y2x_vec, g_x, P1, P2);
-        SAGA_LAUNCH_CHECK();
-    }
-    if (g_y) {
-        p2p_grad_gather_kernel<<<dim3((P2 + NG_THREADS - 1) / NG_THREADS, N), NG_THREADS, 0, st>>>(
-            y, x, yidx, y2x_signed, g_y2x_signed, g_y2x_vec, xidx, x2y_signed, g_x2y_signed, g_x2y_vec, g_y, P2, P1);
-        SAGA_LAUNCH_CHECK();
-    }
+    int rc;
+    if (g_x && (rc = p2p_grad_launch(x, y, xidx, x2y_signed, g_x2y_signed, g_x2y_vec, yidx, y2x_signed, g_y2x_signed, g_y2x_vec, g_x, N,
+                                     P1, P2, st)))
+        return rc;
+    if (g_y && (rc = p2p_grad_launch(y, x, yidx, y2x_signed, g_y2x_signed, g_y2x_vec, xidx, x2y_signed, g_x2y_signed, g_x2y_vec, g_y, N,
+                                     P2, P1, st)))
+        return rc;
     return 0;
 }

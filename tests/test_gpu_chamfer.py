@@ -267,6 +267,18 @@ def test_p2p_signed_operator_against_oracle_with_vectors_and_both_gradients():
             assert (out_h[0] >= 0).all() and (out_h[1] >= 0).all()
         out_2, gx_2, gy_2 = run('cuda', torch.float32, point2point_signed, normals)
         assert torch.equal(gx_2, gx_h) and torch.equal(gy_2, gy_h)
+        # the other backward kernel (fixed-order gather instead of fixed-point LDS accumulation; the default for clouds beyond
+        # 2,048 targets): same gradients to float32 rounding, and bit-reproducible too
+        import os
+        os.environ['SAGA_P2P_GATHER'] = '1'
+        try:
+            _, gx_g, gy_g = run('cuda', torch.float32, point2point_signed, normals)
+            _, gx_g2, gy_g2 = run('cuda', torch.float32, point2point_signed, normals)
+        finally:
+            del os.environ['SAGA_P2P_GATHER']
+        assert torch.equal(gx_g, gx_g2) and torch.equal(gy_g, gy_g2)
+        np.testing.assert_allclose(gx_g.numpy(), gx_h.numpy(), rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(gy_g.numpy(), gy_h.numpy(), rtol=1e-5, atol=1e-6)
     # only x needs a gradient (the SAGA call sites): y's gradient is not computed
     xr = x.cuda().requires_grad_(True)
     o = point2point_signed(xr, y.cuda(), xn.cuda(), yn.cuda())
