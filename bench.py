@@ -117,6 +117,9 @@ def parse():
                          'the loss reads (the dense vertex gradient is zero everywhere else)')
     ap.add_argument('--local-weights', action='store_true',
                     help='synthetic skinning weights with mesh-like locality (runs of vertices share their joints); reported separately')
+    ap.add_argument('--mesh-faces', action='store_true',
+                    help='synthetic template + faces of a mesh-like tube (face corners a few ids apart) instead of random points joined by '
+                         'random triangles; reported separately')
     ap.add_argument('--cpu-seconds', type=float, default=7.0,
                     help='CPU baseline: time budget of EACH of its two legs (B=1 reference semantics, B=64 batched)')
     return ap.parse_args()
@@ -137,6 +140,11 @@ def build_problem(B, n_obj, rank, model_root, device, loss_vertices_only=False):
     data = dict(markers=cu(mk), mc=cu(mc), oc=cu(oc), vo=cu(vo), no=cu(no))
     data['problem'] = op.make_problem(data['markers'], data['vo'], data['no'], data['oc'], data['mc'])
     return op, vp, data
+
+
+def ring_size(op):
+    """Vertices the hand's vertex normals read (every corner of a face touching a hand vertex) on the model in use."""
+    return int(op.tables.struct_for_mesh(op.bm.faces, op.bm.num_verts).n_ring)
 
 
 def step(op, d, optimizer=None):
@@ -210,7 +218,7 @@ def main():
 
     B, n_obj = args.batch, args.obj_points
     tmp = tempfile.TemporaryDirectory()
-    write_body_model(tmp.name, gender='male', seed=7, local_weights=args.local_weights)
+    write_body_model(tmp.name, gender='male', seed=7, local_weights=args.local_weights, mesh_faces=args.mesh_faces)
     op, vp, d = build_problem(B, n_obj, rank, tmp.name, str(device), args.loss_vertices_only)
     op.sparse_backward = bool(args.sparse_backward) and not args.autograd
     V_eval = op.bm.num_verts
@@ -279,6 +287,8 @@ def main():
                                       'VARIANT: only the %d loss vertices of 10475 are evaluated' % V_eval, n_obj),
                        'skinning_weights': ('VARIANT: 4 non-zeros per vertex, runs of vertices share their joints (mesh-like)' if args.local_weights
                                             else '4 non-zeros per vertex at random joints (SURVEY 8d synthetic model)'),
+                       'faces': ('VARIANT: mesh-like tube (face corners a few ids apart; hand ring %d vertices)' if args.mesh_faces else
+                                 'random triangles (SURVEY 8d synthetic model; hand ring %d vertices)') % ring_size(op),
                        'driver': ('torch autograd + torch.optim.Adam' if args.autograd else
                                   'VARIANT: saga_fit_step_sparse (backward over the %d loss vertices only)' % op.tables.n_unique
                                   if args.sparse_backward else 'saga_fit_step (one kernel sequence)'),
@@ -293,14 +303,14 @@ def main():
                          'traffic': None, 'traffic_source': None,
                          'algorithmic_bytes': int(B * 3 * V_eval * 4 + B * 512 * 4 + 3 * V_eval * 512 * 4)},
         }
-        if args.loss_vertices_only or args.sparse_backward or args.local_weights or args.autograd:
+        if args.loss_vertices_only or args.sparse_backward or args.local_weights or args.autograd or args.mesh_faces:
             out['roofline']['traffic_source'] = 'not profiled for this variant'
         else:
             out['roofline']['traffic'], out['roofline']['traffic_source'] = pmc_traffic(B, n_obj, V_eval)
         if args.sparse_backward:        # the dense algorithmic figures do not describe this variant's backward kernels
             for k in ('blend_gemm_bwd', 'skin_bwd', 'grasp_loss_bwd'):
                 out['config']['stages'].pop(k, None)
-        if not (args.sparse_backward or args.loss_vertices_only or args.autograd or args.local_weights):
+        if not (args.sparse_backward or args.loss_vertices_only or args.autograd or args.local_weights or args.mesh_faces):
             out['config']['variants_reported_separately'] = (
                 'bench.py --sparse-backward (saga_fit_step_sparse: same full-mesh forward, backward over the loss vertices only; '
                 'profiles/round1_k_sparse_backward_bench.json: 2.9-3.0 ms per iteration) and --loss-vertices-only; never the headline')

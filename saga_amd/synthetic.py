@@ -65,9 +65,39 @@ def _random_faces(rng, n_verts, n_faces):
     return faces
 
 
+def _tube_mesh(rng, n_verts, n_faces, cols=25):
+    """A mesh-like stand-in for the body surface: vertices on a closed tube (rings of ``cols`` vertices stacked along z, radius
+    varying smoothly), numbered ring by ring, faces joining each ring to the next -- so that, as on a real scan-derived mesh,
+    the corners of a face are a few ids apart, a vertex has valence ~6, and a run of ids (the hand: 7331..8128) is a compact
+    patch with a thin ring of neighbours.  -> (v_template [V,3], faces [>= n_faces, 3])."""
+    V = int(n_verts)
+    rows = (V + cols - 1) // cols
+    r, c = np.arange(V) // cols, np.arange(V) % cols
+    theta = 2 * np.pi * c / cols
+    z = -0.85 + 1.7 * r / max(rows - 1, 1)
+    rad = 0.5 + 0.5 * np.sin(np.pi * r / max(rows - 1, 1)) + 0.05 * np.sin(11 * z)
+    v = np.stack([0.15 * rad * np.cos(theta), 0.1 * rad * np.sin(theta), z], 1) + rng.normal(0, 2e-3, (V, 3))
+    faces = []
+    vid = lambda rr, cc: rr * cols + (cc % cols)
+    for rr in range(rows - 1):
+        for cc in range(cols):
+            a, b, d, e = vid(rr, cc), vid(rr, cc + 1), vid(rr + 1, cc), vid(rr + 1, cc + 1)
+            if max(a, b, d, e) >= V:
+                continue
+            faces.append((a, b, d))
+            faces.append((b, e, d))
+    faces = np.asarray(faces, dtype=np.int64)
+    extra = max(n_faces - faces.shape[0], 0)              # caps / fillers: fans over the first ring
+    if extra:
+        k = np.arange(extra) % max(cols - 2, 1)
+        faces = np.concatenate([faces, np.stack([np.zeros(extra, np.int64), k + 1, k + 2], 1)])
+    return v, faces
+
+
 def make_body_model(seed=7, n_verts=NUM_VERTS_SMPLX, n_faces=NUM_FACES_SMPLX,
-                    weights_nnz=4, dense_weights=False, local_weights=False, n_shape=20, dtype=np.float32):
-    """Random arrays with the layout of a SMPL-X ``.npz`` (10 shape + 10 expression dirs)."""
+                    weights_nnz=4, dense_weights=False, local_weights=False, mesh_faces=False, n_shape=20, dtype=np.float32):
+    """Random arrays with the layout of a SMPL-X ``.npz`` (10 shape + 10 expression dirs).  ``mesh_faces``: template and faces
+    of a mesh-like tube (:func:`_tube_mesh`) instead of SURVEY 8d's random points joined by random triangles."""
     rng = np.random.default_rng(seed)
     V, J = int(n_verts), NUM_JOINTS
     v_template = rng.uniform([-0.3, -0.15, -0.85], [0.3, 0.15, 0.85], size=(V, 3))
@@ -105,6 +135,8 @@ def make_body_model(seed=7, n_verts=NUM_VERTS_SMPLX, n_faces=NUM_FACES_SMPLX,
         return q
 
     faces = _random_faces(rng, V, n_faces)
+    if mesh_faces:
+        v_template, faces = _tube_mesh(rng, V, n_faces)
     F = faces.shape[0]
     lmk_faces_idx = rng.integers(0, F, NUM_LANDMARKS)
     lmk_bary = rng.dirichlet(np.ones(3), NUM_LANDMARKS)

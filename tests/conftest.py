@@ -45,3 +45,12 @@ def small_model_dir(tmp_path_factory):
     root = tmp_path_factory.mktemp('body_models_small')
     write_body_model(str(root), gender='male', seed=3, n_verts=203, n_faces=390, dense_weights=True)
     return str(root)
+
+
+@pytest.fixture(scope='session')
+def mesh_model_dir(tmp_path_factory):
+    """Full-size synthetic SMPL-X whose template and faces are a mesh-like tube (face corners a few ids apart) with local weights."""
+    from saga_amd.synthetic import write_body_model
+    root = tmp_path_factory.mktemp('body_models_mesh')
+    write_body_model(str(root), gender='male', seed=7, mesh_faces=True, local_weights=True)
+    return str(root)

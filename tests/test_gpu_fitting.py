@@ -61,6 +61,41 @@ def test_loss_and_gradients_match_oracle(body_model_dir, stage, fused):
         assert e < 2e-3, (k, e)
 
 
+def test_mesh_like_model_step_matches_oracle_and_standalone_kernels(mesh_model_dir):
+    """The mesh-like variant of the synthetic model (tube template, faces joining neighbouring ids, local skinning weights: the
+    hand's face ring is ~900 vertices instead of 6,485): one native stage-3 step against the oracle (loss 1e-4) and against the
+    SAGA_FIT_NO_PRE=1 path (bit for bit)."""
+    import os
+    B = 3
+    op, vp, idx, var_np, d = _setup(mesh_model_dir, B)
+    op.bm = op.bm_male
+    ring = op.tables.struct_for_mesh(op.bm.faces, op.bm.num_verts).n_ring
+    assert 778 < ring < 1200, ring
+    cu = lambda a: torch.from_numpy(a).cuda()
+    res = []
+    for no_pre in (False, True):
+        op.reset()
+        op.set_variables(var_np)
+        prob = op.make_problem(cu(d['markers']), cu(d['verts_o']), cu(d['normals_o']), cu(d['oc']), cu(d['mc']))
+        terms = torch.zeros(B, 16, device='cuda')
+        os.environ['SAGA_FIT_NO_PRE' if no_pre else 'SAGA_FIT_PRE'] = '1'      # (the ring path is not the default on mesh-like faces)
+        try:
+            loss, mk = op.native_step(2, prob, terms)
+        finally:
+            os.environ.pop('SAGA_FIT_NO_PRE', None)
+            os.environ.pop('SAGA_FIT_PRE', None)
+        res.append((loss.clone(), mk.clone(), terms.clone(), op.vars.clone(), op.workspace_view('hand_normals', 2048, (B, 778, 3)).clone()))
+    for a, b_ in zip(res[0], res[1]):
+        assert torch.equal(a, b_)
+    bm = load_oracle_model(mesh_model_dir, B, dtype=torch.float64)
+    var = {k: torch.from_numpy(v).double() for k, v in var_np.items()}
+    t = lambda a: torch.from_numpy(a).double()
+    total, ld, cnt, aux = loss_ref.loss_batched(bm, var, vp.weights_dict(torch.float64), idx, t(d['markers']), t(d['verts_o']),
+                                                t(d['normals_o']), t(d['oc']), t(d['mc']), 2)
+    np.testing.assert_allclose(res[0][0].cpu().numpy(), total.numpy(), rtol=LOSS_RTOL)
+    assert (res[0][4].cpu().double() - aux['rh_normals'].double()).abs().max() < 1e-4
+
+
 def test_short_fitting_trajectory_matches_oracle(body_model_dir):
     """A few Adam iterations per stage from the reference's reset state: per-iteration loss curves agree."""
     B = 2
