@@ -489,6 +489,11 @@ __global__ __launch_bounds__(DS_THREADS, 4) void skin_bwd_sparse_kernel(
     __shared__ __attribute__((aligned(16))) float sX[DS_VR * 6];     // phase 1/2: [vertex][g.xyz, p.xyz]; phase 3: [12][DS_THREADS]
     __shared__ __attribute__((aligned(16))) float sA[NJ * 12];
     __shared__ float sG[DS_THREADS / 64][4];
+#ifdef DS_EXP_PAD       // timing experiment: extra LDS per block (occupancy of a replicated joint table)
+    __shared__ float sPad[DS_EXP_PAD];
+    if (V < 0) sPad[threadIdx.x] = (float)Npad;
+    if (V < -1) g_vposed[threadIdx.x] = sPad[threadIdx.x + 1];
+#endif
     const int b = blockIdx.x, tid = threadIdx.x;
     const int r_begin = blockIdx.y * rpb, r_end = min(n_ranges, r_begin + rpb);
     for (int i = tid; i < NJ * 12; i += DS_THREADS) sA[i] = A[(size_t)b * (NJ * 12) + i];
@@ -551,7 +556,11 @@ __global__ __launch_bounds__(DS_THREADS, 4) void skin_bwd_sparse_kernel(
 #pragma unroll
             for (int k = 0; k < 9; ++k) T[k] = 0.f;
             if (KW4) {
+#ifdef DS_EXP_P1        // timing experiment: conflict-free joint reads (wrong results)
+                const int jj[4] = {(tid & 15) + (ji[i].x & 16), (tid & 15) + (ji[i].y & 16), (tid & 15) + (ji[i].z & 16), (tid & 15) + (ji[i].w & 16)};
+#else
                 const int jj[4] = {ji[i].x, ji[i].y, ji[i].z, ji[i].w};
+#endif
                 const float ww[4] = {wv[i].x, wv[i].y, wv[i].z, wv[i].w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -604,7 +613,11 @@ __global__ __launch_bounds__(DS_THREADS, 4) void skin_bwd_sparse_kernel(
             for (int u = 0; u < 4; ++u) en[u] = e[(size_t)(cn + u) * DS_THREADS];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+#ifdef DS_EXP_P2        // timing experiment: conflict-free row reads (wrong results)
+                const float2* row = reinterpret_cast<const float2*>(sX + (((cur[u].x & 480) + tid) & 511) * 6);
+#else
                 const float2* row = reinterpret_cast<const float2*>(sX + cur[u].x * 6);
+#endif
                 const float2 r0 = row[0], r1 = row[1], r2 = row[2];
                 const float w = __int_as_float(cur[u].y);
                 const float wg0 = w * r0.x, wg1 = w * r0.y, wg2 = w * r1.x;

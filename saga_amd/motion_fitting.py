@@ -75,12 +75,13 @@ class FittingOP:
     ``vposer``, ``smplx_kwargs``, ``indices`` (foot groups), ``body_smooth_loss`` (see the module docstring),
     ``sparse_backward`` (default True: stage 2 differentiates through the vertices its losses read only -- same gradients up
     to summation order, no dense [S*T,V,3] gradient; switched off automatically with a ``body_smooth_loss`` hook, which may
-    read any vertex)."""
+    read any vertex), ``reduced_forward`` (default True, with ``sparse_backward``: stage 2 evaluates only the vertices its losses
+    and the hand normals read -- the same numbers, see ``_make_picker``)."""
 
     def __init__(self, fittingconfig):
         cfg = dict(T=61, gender='male', device='cuda', n_seq=1, start_t=30, init_lr_stage1=0.1, init_lr_stage2=0.01,
                    num_iter=[100, 300], body_model_path='./body_utils/body_models', vposer=None, smplx_kwargs={},
-                   indices=None, body_smooth_loss=None, sparse_backward=True,
+                   indices=None, body_smooth_loss=None, sparse_backward=True, reduced_forward=True,
                    stage1_weight_loss_rec_markers=1.0, stage1_weight_loss_vposer=0.02, stage1_weight_loss_shape=0.01,
                    stage1_weight_loss_hand=0.01,
                    stage2_weight_loss_rec_markers=0.1, stage2_weight_loss_end_markers_fit=10, stage2_weight_loss_vposer=0.02,
@@ -95,16 +96,9 @@ class FittingOP:
             raise RuntimeError('saga_amd.motion_fitting.FittingOP runs on a ROCm GPU only (device=%s)' % self.device)
         S, T = self.n_seq, self.T
 
-        def make(batch):
-            bm = _smplx.create(self.body_model_path, model_type='smplx', gender=self.gender, ext='npz', num_pca_comps=24,
-                               create_global_orient=True, create_body_pose=True, create_betas=True,
-                               create_left_hand_pose=True, create_right_hand_pose=True, create_expression=True,
-                               create_jaw_pose=True, create_leye_pose=True, create_reye_pose=True, create_transl=True,
-                               batch_size=batch, **self.smplx_kwargs)
-            return bm.to(self.device).eval()
-
-        self.smplx_model = make(S)                    # one frame of every sequence (stage 1)
-        self.smplx_model_batch = make(S * T)          # every frame of every sequence (stage 2)
+        self.smplx_model = self._make_body_model(S)                    # one frame of every sequence (stage 1)
+        self.smplx_model_batch = self._make_body_model(S * T)          # every frame of every sequence (stage 2)
+        self._loss_model = None                       # stage 2, the vertices its losses read only (see _make_picker)
         if self.vposer is None:
             self.vposer = VPoserDecoder(seed=0)
         self.vposer_model = self.vposer.to(self.device).eval()
@@ -117,6 +111,16 @@ class FittingOP:
         self.markers_ids_143 = as_ids(self.markers_ids_143)
         self._picker = None
         self.init_param_t()
+
+    def _make_body_model(self, batch, **extra):
+        kw = dict(self.smplx_kwargs)
+        kw.update(extra)
+        bm = _smplx.create(self.body_model_path, model_type='smplx', gender=self.gender, ext='npz', num_pca_comps=24,
+                           create_global_orient=True, create_body_pose=True, create_betas=True,
+                           create_left_hand_pose=True, create_right_hand_pose=True, create_expression=True,
+                           create_jaw_pose=True, create_leye_pose=True, create_reye_pose=True, create_transl=True,
+                           batch_size=batch, **kw)
+        return bm.to(self.device).eval()
 
     # ---- variables -----------------------------------------------------------------------------------------------------
     def init_param_t(self):
@@ -186,7 +190,29 @@ class FittingOP:
     def _make_picker(self, rhand_verts):
         sets = {'markers': self.markers_ids, 'markers_143': self.markers_ids_143, 'rhand': rhand_verts}
         sets.update(self.foot_groups)
-        self._picker = ml.VertexPicker(sets, self.device)
+        self._picker = pk = ml.VertexPicker(sets, self.device)
+        self._loss_model = None
+        if not (self.sparse_backward and self.reduced_forward and self.body_smooth_loss is None):
+            return
+        # Stage 2 reads ~1,100 vertices, and the normals of the right hand and its palm markers read the corners of the faces
+        # around those: evaluate that set only (a vertex-subset body model: its rows are bit-identical to the same rows of the
+        # full mesh and it keeps every face inside the set, in order, so the normals are the full mesh's too).
+        faces = np.asarray(self.smplx_model_batch.faces)
+        union = pk.union.cpu().numpy()
+        normal_ids = np.unique(np.concatenate([rhand_verts.cpu().numpy(), self.markers_ids_143[-22:].cpu().numpy()]))
+        touched = np.zeros(self.smplx_model_batch.num_verts, dtype=bool)
+        touched[normal_ids] = True
+        ring = np.unique(faces[touched[faces].any(axis=1)])
+        keep = np.union1d(union, ring)
+        if keep.size * 10 > self.smplx_model_batch.num_verts * 9:
+            return                                              # (nearly) the whole mesh anyway
+        key = keep.tobytes()
+        cached = self.__dict__.get('_loss_model_cache')
+        if cached is None or cached[0] != key:
+            cached = self.__dict__['_loss_model_cache'] = (key, self._make_body_model(self.n_seq * self.T, vertex_subset=keep))
+        as_pos = lambda ids: torch.as_tensor(np.searchsorted(keep, ids.cpu().numpy() if torch.is_tensor(ids) else ids),
+                                             dtype=torch.long, device=self.device)
+        self._loss_model = dict(bm=cached[1], grad_rows=as_pos(union), rhand=as_pos(rhand_verts), markers_143=as_pos(self.markers_ids_143))
 
     def stage2_losses(self, markers_rec_T, markers_end_new, rhand_verts, contact_lbl_rec, contact_object, contact_markers,
                       normal_object, verts_object):
@@ -197,7 +223,13 @@ class FittingOP:
         if self._picker is None:
             self._make_picker(rhand_verts)
         pk = self._picker
-        if self.sparse_backward and self.body_smooth_loss is None:
+        bm, normal_ids = self.smplx_model_batch, (rhand_verts, self.markers_ids_143)
+        if self._loss_model is not None:
+            lm = self._loss_model
+            bm, normal_ids = lm['bm'], (lm['rhand'], lm['markers_143'])
+            (verts, sub), _ = gen_body_mesh_v1(p, bm, self.vposer_model, vertex_grad_ids=lm['grad_rows'])
+            verts, sub = verts.reshape(S, T, -1, 3), sub.reshape(S, T, -1, 3)
+        elif self.sparse_backward and self.body_smooth_loss is None:
             # every vertex any term reads, as the differentiable output: the backward runs over those ~1,100 vertices only
             # (the full mesh is still evaluated -- the normals read it -- but carries no gradient)
             (verts, sub), _ = gen_body_mesh_v1(p, self.smplx_model_batch, self.vposer_model, vertex_grad_ids=pk.union)
@@ -215,9 +247,9 @@ class FittingOP:
         terms['rec_markers'] = (markers * mask - markers_rec_T * mask).abs().mean(dim=(1, 2, 3))
         terms['end_markers_fit'] = (markers[:, -1] - markers_end_new).abs().mean(dim=(1, 2))
         terms['skating'] = ml.skating_loss_seq(sub, contact_lbl_rec, {k: pk.pos[k] for k in self.foot_groups})
-        terms['contact'], state = ml.contact_loss_seq(self.smplx_model_batch, start_t, sub, pk.pos['markers_143'], pk.pos['rhand'],
+        terms['contact'], state = ml.contact_loss_seq(bm, start_t, sub, pk.pos['markers_143'], pk.pos['rhand'],
                                                        contact_object, contact_markers, normal_object, verts_object, n_frames=T,
-                                                       full_verts=verts, full_ids=(rhand_verts, self.markers_ids_143))
+                                                       full_verts=verts, full_ids=normal_ids)
         terms['hand_smooth'] = ml.hand_smooth_loss_seq(sub, start_t, pk.pos['rhand'])
         terms['collision'] = ml.collision_loss_seq(state)
         terms['hand_angle'] = ml.angle_loss_seq(state, start_t, T)

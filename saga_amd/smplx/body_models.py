@@ -193,13 +193,14 @@ class SMPLX(nn.Module):
         return h
 
     def subset_handle(self, device, vertex_ids):
-        """``saga_model_t*`` of this (full) model restricted to ``vertex_ids`` (ascending, unique) on ``device``: the model
-        ``saga_fit_step_sparse`` runs its backward on.  Cached per device and id list, freed with the module."""
-        if self.vertex_subset is not None:
-            raise RuntimeError('subset_handle: this module already evaluates a vertex subset')
+        """``saga_model_t*`` of this model restricted to ``vertex_ids`` (rows of ``vertices``: ascending, unique) on
+        ``device``: the model ``saga_fit_step_sparse`` runs its backward on.  Cached per device and id list, freed with the
+        module."""
         ids = np.ascontiguousarray(vertex_ids, dtype=np.int32)
         if ids.ndim != 1 or ids.size == 0 or np.any(np.diff(ids) <= 0) or ids[0] < 0 or ids[-1] >= self.num_verts:
             raise ValueError('subset_handle: vertex ids must be ascending, unique and inside the mesh')
+        if self.vertex_subset is not None:          # ids are rows of THIS module's vertices: a subset of the subset
+            ids = np.ascontiguousarray(self.vertex_subset[ids])
         idx = device.index if device.index is not None else torch.cuda.current_device()
         key = ('subset', idx, ids.tobytes())
         h = self._handles.get(key)

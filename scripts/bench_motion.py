@@ -17,15 +17,17 @@ ap.add_argument('--frames', type=int, default=61)
 ap.add_argument('--iters', type=int, default=5)
 ap.add_argument('--warmup', type=int, default=2)
 ap.add_argument('--dense-backward', action='store_true', help='dense [S*T,V,3] vertex gradient (the form the reference has)')
+ap.add_argument('--full-forward', action='store_true', help='evaluate the whole mesh in the forward (reduced_forward=False)')
+ap.add_argument('--mesh-faces', action='store_true', help='mesh-like synthetic model (id-local faces and weights)')
 a = ap.parse_args()
 S, T, start_t = a.sequences, a.frames, 30
 tmp = tempfile.TemporaryDirectory()
-write_body_model(tmp.name, gender='male', seed=7)
+write_body_model(tmp.name, gender='male', seed=7, mesh_faces=a.mesh_faces, local_weights=a.mesh_faces)
 idx = load_grasp_indices()
 g = torch.Generator().manual_seed(0)
 op = FittingOP(dict(T=T, n_seq=S, start_t=start_t, gender='male', device='cuda', smplx_beta=0.5 * torch.randn(S, 10, generator=g).numpy(),
                     num_iter=[0, 1], markers_ids=idx['markers_f0_p5'], markers_ids_143=idx['markers_143'], body_model_path=tmp.name,
-                    indices=idx, sparse_backward=not a.dense_backward))
+                    indices=idx, sparse_backward=not a.dense_backward, reduced_forward=not a.full_forward))
 lam = torch.linspace(0, 1, T)[None, :, None]
 transl = torch.tensor([0.0, 0.4, 1.0]) + 0.3 * lam * torch.randn(S, 1, 3, generator=g)
 rot6 = convert_to_6D_all(torch.tensor([[0.0, 1.6, 3.14]]))[None].expand(S, T, 6).contiguous()
@@ -53,6 +55,8 @@ run(a.iters)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.iters
 print(json.dumps({'config': 'GraspMotion-Opt stage 2, %d sequences x %d frames' % (S, T), 'bodies_per_iteration': S * T, 'backward': 'dense' if a.dense_backward else 'loss vertices only',
+                  'vertices_evaluated': (op._loss_model['bm'].num_verts if op._loss_model is not None else op.smplx_model_batch.num_verts),
+                  'model': 'mesh-like faces, local weights' if a.mesh_faces else 'SURVEY synthetic (random faces and joints)',
                   'ms_per_iteration': round(dt * 1e3, 2), 'frame_iterations_per_s': round(S * T / dt, 1),
                   'note': 'each timed call builds a fresh Adam (as the reference does per sequence); data synthetic',
                   'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))

@@ -184,35 +184,46 @@ def test_motion_stage2_matches_oracle(body_model_dir):
             np.testing.assert_allclose(a.detach().cpu().numpy(), b.numpy(), atol=2e-3, rtol=0, err_msg='%s seq %d' % (name, s))
 
 
-def test_motion_stage2_sparse_backward_matches_dense(body_model_dir):
+@pytest.mark.parametrize('mesh', ['random_faces', 'mesh_like'])
+def test_motion_stage2_sparse_backward_matches_dense(body_model_dir, mesh_model_dir, mesh):
     """Stage 2 with ``sparse_backward`` (smplx forward(vertex_grad_ids=...): only the vertices the losses read carry a
-    gradient, backward on the subset model) against the dense autograd path: equal losses, gradients equal to rounding."""
+    gradient, backward on the subset model) against the dense autograd path: equal losses, gradients equal to rounding.
+    ``reduced_forward`` (the forward also runs over the loss vertices and the hand's face ring only) changes no bit of
+    either."""
+    model_dir = body_model_dir if mesh == 'random_faces' else mesh_model_dir
     S, Tn, start_t = 2, 9, 4
-    idx, _, vposer, prob = _fit_problem(body_model_dir, S, Tn, start_t, seed=60)
+    idx, _, vposer, prob = _fit_problem(model_dir, S, Tn, start_t, seed=60)
     g = torch.Generator().manual_seed(5)
     transl = torch.tensor([0.0, 0.4, 1.0]) + 0.02 * torch.rand(S, Tn, 3, generator=g)
     rot6 = torch.tensor([-1., 0, 0, 0, 0, 1]).expand(S, Tn, 6) + 0.05 * torch.randn(S, Tn, 6, generator=g)
     other = 0.1 * torch.randn(S, Tn, 80, generator=g)
     shape = prob['beta'][:, None].expand(S, Tn, 10).float().contiguous()
     f = lambda a, *sh: torch.as_tensor(a).cuda().float().reshape(*sh)
-    res = {}
-    for sparse in (False, True):
-        op = _hip_op(body_model_dir, idx, vposer, prob, S, Tn, start_t, [0, 1])
-        op.sparse_backward = sparse
+    res, n_eval = {}, {}
+    for mode in ('dense', 'sparse', 'reduced'):
+        op = _hip_op(model_dir, idx, vposer, prob, S, Tn, start_t, [0, 1])
+        op.sparse_backward, op.reduced_forward = mode != 'dense', mode == 'reduced'
         op.init_param_T(transl, rot6, other, shape.numpy())
         rh = torch.as_tensor(idx['rhand'], dtype=torch.long, device='cuda')
         total, terms = op.stage2_losses(f(prob['markers_rec'], S, Tn, -1, 3), f(prob['markers_end'], S, -1, 3), rh,
                                         f(prob['lbl'], S, Tn, 4), f(prob['c_obj'], S, -1), f(prob['c_mk'], S, -1),
                                         f(prob['no'], S, Tn - start_t, 2048, 3), f(prob['vo'], S, Tn - start_t, 2048, 3))
         total.sum().backward()
-        res[sparse] = (total.detach(), {k: v.detach() for k, v in terms.items()},
-                       [t.grad.clone() for t in (op.transl_opt_T, op.rot_6d_opt_T, op.other_params_opt_T)])
-    assert torch.equal(res[True][0], res[False][0])
-    for k in res[False][1]:
-        assert torch.equal(res[True][1][k], res[False][1][k]), k
-    for a, b in zip(res[True][2], res[False][2]):
-        assert b.abs().max() > 0
-        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
+        res[mode] = (total.detach(), {k: v.detach() for k, v in terms.items()},
+                     [t.grad.clone() for t in (op.transl_opt_T, op.rot_6d_opt_T, op.other_params_opt_T)])
+        n_eval[mode] = op._loss_model['bm'].num_verts if op._loss_model is not None else op.smplx_model_batch.num_verts
+    assert n_eval['reduced'] < n_eval['sparse'] == n_eval['dense'] == 10475
+    if mesh == 'mesh_like':
+        assert n_eval['reduced'] < 3000, n_eval           # ~1,100 loss vertices + the hand's ring
+    for mode in ('sparse', 'reduced'):
+        assert torch.equal(res[mode][0], res['dense'][0])
+        for k in res['dense'][1]:
+            assert torch.equal(res[mode][1][k], res['dense'][1][k]), k
+        for a, b in zip(res[mode][2], res['dense'][2]):
+            assert b.abs().max() > 0
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
+    for a, b in zip(res['reduced'][2], res['sparse'][2]):
+        assert torch.equal(a, b)
 
 
 def test_motion_fitting_sequences_are_independent(body_model_dir):
