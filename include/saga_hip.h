@@ -168,6 +168,7 @@ int saga_chamfer_bwd(const float* x, const float* y, const int32_t* idx1, const 
  * the nearest-neighbour search above, then x2y = x - y[xidx], y2x = y - x[yidx], their norms, and the sign of the dot product
  * with the OTHER cloud's normal at the neighbour (a NULL normal array leaves that direction unsigned; sign(0) = 0).
  *   y2x_signed [N,P2], x2y_signed [N,P1], yidx [N,P2], xidx [N,P1] int32; y2x_vec [N,P2,3] / x2y_vec [N,P1,3] optional (NULL).
+ *   y2x_signed = yidx = y2x_vec = NULL: the y -> x direction is not searched (for callers that discard it, MotionFill :154).
  * Backward: gradients of the signed distances and / or of the difference vectors (each may be NULL) -> g_x [N,P1,3], g_y
  * [N,P2,3] (written; either may be NULL).  The reference's gather backward is a scatter-add with float atomics; here it is a
  * fixed-order gather: bit-reproducible.  A point that coincides with its neighbour gets no distance gradient (torch: NaN). */
@@ -178,6 +179,18 @@ int saga_p2p_signed_bwd(const float* x, const float* y, const int32_t* yidx, con
                         const float* y2x_signed, const float* x2y_signed,
                         const float* g_y2x_signed, const float* g_x2y_signed, const float* g_y2x_vec, const float* g_x2y_vec,
                         float* g_x, float* g_y, int N, int P1, int P2, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row picks.  Replaces the per-set vertex gathers of the GraspMotion-Opt objective and their autograd backward
+ * (MotionFill/models/fittingop.py:356-409: body_verts[:, markers], [:, rhand], [:, heel/toe ids] ...: one index_select per
+ * set, each with a zero-filled full-size gradient and an index_add in the backward).
+ *   saga_pick_rows_fwd : src [N,U,3], pos [P] (values in [0,U), repeats allowed) -> out [N,P,3] = src[:, pos]
+ *   saga_pick_rows_bwd : g_out [N,P,3] -> g_src [N,U,3] (overwritten) = sum over the picks of each row, in ascending pick
+ *                        order (inv_ptr [U+1], inv_idx [P]: CSR of pick positions per source row) -- deterministic
+ * ------------------------------------------------------------------------------------------ */
+int saga_pick_rows_fwd(const float* src, const int32_t* pos, float* out, int N, int U, int P, void* stream);
+int saga_pick_rows_bwd(const float* g_out, const int32_t* inv_ptr, const int32_t* inv_idx, float* g_src, int N, int U, int P,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Vertex normals.  Replaces Open3D TriangleMesh.compute_vertex_normals()

@@ -105,6 +105,8 @@ PROTOTYPES = {
                                            ctypes.c_int, c_stream]),
     'saga_p2p_signed_bwd': (ctypes.c_int, [c_float_p, c_float_p, c_int_p, c_int_p] + [c_float_p] * 8 + [ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, c_stream]),
+    'saga_pick_rows_fwd': (ctypes.c_int, [c_float_p, c_int_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    'saga_pick_rows_bwd': (ctypes.c_int, [c_float_p, c_int_p, c_int_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
     'saga_vertex_normals': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_int, c_stream]),
     'saga_vertex_normals_subset': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_int_p, ctypes.c_int, c_float_p,
                                                   ctypes.c_int, c_stream]),

@@ -256,19 +256,26 @@ extern "C" int saga_p2p_signed_fwd(const float* x, const float* y, const float* 
     SAGA_CHECK_ARG(N >= 0 && P1 >= 0 && P2 >= 0, "saga_p2p_signed_fwd: negative size");
     if (N == 0 || (P1 == 0 && P2 == 0)) return 0;
     SAGA_CHECK_ARG(P1 > 0 && P2 > 0, "saga_p2p_signed_fwd: empty cloud (P1=%d, P2=%d) has no nearest neighbour", P1, P2);
-    SAGA_CHECK_ARG(x && y && y2x_signed && x2y_signed && yidx && xidx, "saga_p2p_signed_fwd: null argument");
+    SAGA_CHECK_ARG(x && y && x2y_signed && xidx, "saga_p2p_signed_fwd: null argument");
+    // a caller that reads the x -> y direction only (the marker call of the GraspMotion-Opt contact loss discards the other,
+    // MotionFill/models/fittingop.py:154) passes y2x_signed = yidx = y2x_vec = NULL: that search is then not run
+    const bool both = y2x_signed != nullptr;
+    SAGA_CHECK_ARG(both ? yidx != nullptr : (yidx == nullptr && y2x_vec == nullptr),
+                   "saga_p2p_signed_fwd: y2x_signed, yidx (and y2x_vec) are given together or all NULL");
     SAGA_CHECK_ARG(N <= 65535, "saga_p2p_signed_fwd: batch %d exceeds 65535", N);
     hipStream_t st = (hipStream_t)stream;
     void* prof = saga_prof_begin(SAGA_PROF_CHAMFER, stream);
     int rc = launch_scan(x, y, nullptr, xidx, N, P1, P2, st);
-    if (!rc) rc = launch_scan(y, x, nullptr, yidx, N, P2, P1, st);
+    if (!rc && both) rc = launch_scan(y, x, nullptr, yidx, N, P2, P1, st);
     saga_prof_end(prof);
     if (rc) return rc;
     // x2y = x - y[xidx], signed by y_normals[xidx] (:76-81); y2x = y - x[yidx], signed by x_normals[yidx] (:68-74)
     p2p_signed_kernel<<<(unsigned)(((size_t)N * P1 + 255) / 256), 256, 0, st>>>(x, y, y_normals, xidx, x2y_signed, x2y_vec, N, P1, P2);
     SAGA_LAUNCH_CHECK();
-    p2p_signed_kernel<<<(unsigned)(((size_t)N * P2 + 255) / 256), 256, 0, st>>>(y, x, x_normals, yidx, y2x_signed, y2x_vec, N, P2, P1);
-    SAGA_LAUNCH_CHECK();
+    if (both) {
+        p2p_signed_kernel<<<(unsigned)(((size_t)N * P2 + 255) / 256), 256, 0, st>>>(y, x, x_normals, yidx, y2x_signed, y2x_vec, N, P2, P1);
+        SAGA_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -448,7 +455,9 @@ extern "C" int saga_p2p_signed_bwd(const float* x, const float* y, const int32_t
                                    void* stream) {
     SAGA_CHECK_ARG(N >= 0 && P1 >= 0 && P2 >= 0, "saga_p2p_signed_bwd: negative size");
     if (N == 0 || P1 == 0 || P2 == 0) return 0;
-    SAGA_CHECK_ARG(x && y && yidx && xidx && y2x_signed && x2y_signed, "saga_p2p_signed_bwd: null argument");
+    SAGA_CHECK_ARG(x && y && xidx && x2y_signed, "saga_p2p_signed_bwd: null argument");
+    SAGA_CHECK_ARG((yidx && y2x_signed) || (!g_y2x_signed && !g_y2x_vec),
+                   "saga_p2p_signed_bwd: gradients of the y -> x outputs need yidx and y2x_signed");
     SAGA_CHECK_ARG(g_x || g_y, "saga_p2p_signed_bwd: no gradient requested");
     SAGA_CHECK_ARG(N <= 65535, "saga_p2p_signed_bwd: batch %d exceeds 65535", N);
     hipStream_t st = (hipStream_t)stream;

@@ -15,7 +15,7 @@ class _P2PSigned(torch.autograd.Function):
     norms + normal-dot signs forward; a deterministic (fixed-order gather, no atomics) backward to both clouds."""
 
     @staticmethod
-    def forward(ctx, x, y, x_normals, y_normals, want_vec):
+    def forward(ctx, x, y, x_normals, y_normals, want_vec, both=True):
         _lib.require_device(x, y, x_normals, y_normals)
         xc, yc = x.detach().contiguous(), y.detach().contiguous()
         xn = None if x_normals is None else x_normals.detach().contiguous()
@@ -23,15 +23,15 @@ class _P2PSigned(torch.autograd.Function):
         N, P1, _ = xc.shape
         P2 = yc.shape[1]
         f32, i32 = dict(device=xc.device, dtype=torch.float32), dict(device=xc.device, dtype=torch.int32)
-        y2x_s, x2y_s = torch.empty(N, P2, **f32), torch.empty(N, P1, **f32)
-        yidx, xidx = torch.empty(N, P2, **i32), torch.empty(N, P1, **i32)
-        y2x_v = torch.empty(N, P2, 3, **f32) if want_vec else None
+        y2x_s, x2y_s = (torch.empty(N, P2, **f32) if both else None), torch.empty(N, P1, **f32)
+        yidx, xidx = (torch.empty(N, P2, **i32) if both else None), torch.empty(N, P1, **i32)
+        y2x_v = torch.empty(N, P2, 3, **f32) if (want_vec and both) else None
         x2y_v = torch.empty(N, P1, 3, **f32) if want_vec else None
         P = _lib.ptr
         _lib.call('saga_p2p_signed_fwd', xc.device, P(xc), P(yc), P(xn), P(yn), P(y2x_s), P(x2y_s), P(yidx), P(xidx), P(y2x_v),
                   P(x2y_v), N, P1, P2)
         ctx.save_for_backward(xc, yc, yidx, xidx, y2x_s, x2y_s)
-        ctx.mark_non_differentiable(yidx, xidx)
+        ctx.mark_non_differentiable(*[t for t in (yidx, xidx) if t is not None])
         ctx.set_materialize_grads(False)
         if want_vec:
             return y2x_s, x2y_s, yidx, xidx, y2x_v, x2y_v
@@ -42,7 +42,7 @@ class _P2PSigned(torch.autograd.Function):
         xc, yc, yidx, xidx, y2x_s, x2y_s = ctx.saved_tensors
         need_x, need_y = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if not (need_x or need_y) or all(g is None for g in (g_y2x_s, g_x2y_s, g_y2x_v, g_x2y_v)):
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         c = lambda g: None if g is None else g.contiguous()
         gx = torch.empty_like(xc) if need_x else None
         gy = torch.empty_like(yc) if need_y else None
@@ -50,20 +50,80 @@ class _P2PSigned(torch.autograd.Function):
         P = _lib.ptr
         _lib.call('saga_p2p_signed_bwd', xc.device, P(xc), P(yc), P(yidx), P(xidx), P(y2x_s), P(x2y_s), P(c(g_y2x_s)), P(c(g_x2y_s)),
                   P(c(g_y2x_v)), P(c(g_x2y_v)), P(gx), P(gy), N, P1, yc.shape[1])
-        return gx, gy, None, None, None
+        return gx, gy, None, None, None, None
 
 
-def point2point_signed(x, y, x_normals=None, y_normals=None, return_vector=False):
+def point2point_signed(x, y, x_normals=None, y_normals=None, return_vector=False, directions='both'):
     """Signed distance between two point clouds (``utils/train_helper.py:17-86``: same arguments, return order and
     ``ValueError``).  x [N,P1,3], y [N,P2,3] -> y2x_signed [N,P2], x2y_signed [N,P1], yidx_near [N,P2] int32,
     xidx_near [N,P1] int32 (, y2x [N,P2,3], x2y [N,P1,3]).  Differentiable w.r.t. ``x`` and ``y`` (not the normals: only
-    the sign of their dot product is used)."""
+    the sign of their dot product is used).  ``directions='x2y'`` (not in the reference): the y -> x search is not run and
+    its outputs (y2x_signed, yidx_near, y2x) are None -- for call sites that discard them."""
+    if directions not in ('both', 'x2y'):
+        raise ValueError("directions must be 'both' or 'x2y'")
     N, P1, D = x.shape
     if y.shape[0] != N or y.shape[2] != D:
         raise ValueError("y does not have the correct shape.")
     if D != 3:
         raise NotImplementedError('point2point_signed on the HIP path takes 3-D points (got D=%d)' % D)
-    return _P2PSigned.apply(x, y, x_normals, y_normals, bool(return_vector))
+    return _P2PSigned.apply(x, y, x_normals, y_normals, bool(return_vector), directions == 'both')
+
+
+class _PickRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, picker):
+        _lib.require_device(src)
+        lead, (U, D) = src.shape[:-2], src.shape[-2:]
+        if D != 3 or U != picker.n_rows:
+            raise ValueError('pick_rows: src must be [..., %d, 3], got %s' % (picker.n_rows, tuple(src.shape)))
+        sc = src.detach().contiguous()
+        N = sc.numel() // (U * 3)
+        out = torch.empty(lead + (picker.n_picks, 3), device=sc.device, dtype=torch.float32)
+        pos, _, _ = picker.tables(sc.device)
+        _lib.call('saga_pick_rows_fwd', sc.device, _lib.ptr(sc), _lib.ptr(pos), _lib.ptr(out), N, U, picker.n_picks)
+        ctx.picker, ctx.src_shape = picker, src.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        picker = ctx.picker
+        g = g.contiguous()
+        gs = torch.empty(ctx.src_shape, device=g.device, dtype=torch.float32)
+        _, inv_ptr, inv_idx = picker.tables(g.device)
+        N = gs.numel() // (picker.n_rows * 3)
+        _lib.call('saga_pick_rows_bwd', g.device, _lib.ptr(g), _lib.ptr(inv_ptr), _lib.ptr(inv_idx), _lib.ptr(gs), N, picker.n_rows,
+                  picker.n_picks)
+        return gs, None
+
+
+class RowPicker:
+    """Several named row sets of one [..., U, 3] cloud picked by ONE kernel (``saga_pick_rows_fwd``) and differentiated by one
+    deterministic gather (``saga_pick_rows_bwd``).  ``sets``: {name: positions in [0, U)} (repeats and overlaps allowed).
+    ``picker(src)`` -> {name: [..., n, 3]} (views of one buffer; their gradients are concatenated, not zero-padded)."""
+
+    def __init__(self, sets, n_rows):
+        import numpy as np
+        self.names = list(sets)
+        self.sizes = [int(len(sets[k])) for k in self.names]
+        pos = np.concatenate([np.asarray(sets[k].cpu() if torch.is_tensor(sets[k]) else sets[k], dtype=np.int64).reshape(-1)
+                              for k in self.names])
+        if pos.size == 0 or pos.min() < 0 or pos.max() >= n_rows:
+            raise ValueError('RowPicker: positions must lie in [0, %d)' % n_rows)
+        self.n_rows, self.n_picks = int(n_rows), int(pos.size)
+        order = np.argsort(pos, kind='stable')                      # picks of a row in ascending pick order
+        ptr = np.zeros(n_rows + 1, dtype=np.int64)
+        np.add.at(ptr, pos + 1, 1)
+        self._host = (pos.astype(np.int32), np.cumsum(ptr).astype(np.int32), order.astype(np.int32))
+        self._dev = {}
+
+    def tables(self, device):
+        t = self._dev.get(str(device))
+        if t is None:
+            t = self._dev[str(device)] = tuple(torch.from_numpy(a).to(device) for a in self._host)
+        return t
+
+    def __call__(self, src):
+        return dict(zip(self.names, _PickRows.apply(src, self).split(self.sizes, dim=-2)))
 
 
 def vertex_normals(model, verts):

@@ -238,7 +238,8 @@ class FittingOP:
             verts, _ = gen_body_mesh_v1(p, self.smplx_model_batch, self.vposer_model)
             verts = verts.reshape(S, T, -1, 3)
             sub = pk.gather(verts)                               # every vertex any term reads, gathered once
-        markers = sub.index_select(2, pk.pos['markers'])
+        picked = pk.pick(sub)                                    # every set the terms read: one kernel, one backward gather
+        markers = picked['markers']
         mask = torch.ones(1, 1, markers.shape[2], 1, device=self.device)
         mask[:, :, 49:49 + 6] = 0        # hand
         mask[:, :, 33:33 + 6] = 0        # forearm
@@ -246,11 +247,11 @@ class FittingOP:
         terms = {}
         terms['rec_markers'] = (markers * mask - markers_rec_T * mask).abs().mean(dim=(1, 2, 3))
         terms['end_markers_fit'] = (markers[:, -1] - markers_end_new).abs().mean(dim=(1, 2))
-        terms['skating'] = ml.skating_loss_seq(sub, contact_lbl_rec, {k: pk.pos[k] for k in self.foot_groups})
+        terms['skating'] = ml.skating_loss_seq(sub, contact_lbl_rec, {k: pk.pos[k] for k in self.foot_groups}, picked=picked)
         terms['contact'], state = ml.contact_loss_seq(bm, start_t, sub, pk.pos['markers_143'], pk.pos['rhand'],
                                                        contact_object, contact_markers, normal_object, verts_object, n_frames=T,
-                                                       full_verts=verts, full_ids=normal_ids)
-        terms['hand_smooth'] = ml.hand_smooth_loss_seq(sub, start_t, pk.pos['rhand'])
+                                                       full_verts=verts, full_ids=normal_ids, picked=picked)
+        terms['hand_smooth'] = ml.hand_smooth_loss_seq(sub, start_t, pk.pos['rhand'], picked=picked)
         terms['collision'] = ml.collision_loss_seq(state)
         terms['hand_angle'] = ml.angle_loss_seq(state, start_t, T)
         pp = p.reshape(S, T, -1)

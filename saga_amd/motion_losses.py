@@ -11,7 +11,7 @@ convolutional auto-encoder) is a network, not part of this path.
 """
 import torch
 
-from .geometry import point2point_signed, vertex_normals_subset
+from .geometry import RowPicker, point2point_signed, vertex_normals_subset
 
 
 def foot_groups(idx):
@@ -34,21 +34,26 @@ class VertexPicker:
         self.union = torch.unique(torch.cat(list(ids.values())))                       # sorted
         self.pos = {k: torch.searchsorted(self.union, v) for k, v in ids.items()}      # position of each id in the union
         self.ids = ids
+        self.rows = RowPicker(self.pos, int(self.union.shape[0]))      # every set out of the gathered union, one kernel
 
     def gather(self, body_verts):
         return body_verts.index_select(2, self.union)
 
+    def pick(self, union_verts):
+        """{set name: [S,T,n,3]} out of ``gather``'s result (one kernel forward, one deterministic gather backward)."""
+        return self.rows(union_verts)
+
 
 def contact_loss_seq(bm, start_t, body_verts, markers_143, rhand_verts, contact_object, contact_markers, normal_object,
-                     verts_object, n_frames=None, full_verts=None, full_ids=None):
+                     verts_object, n_frames=None, full_verts=None, full_ids=None, picked=None):
     """body_verts [S,T,V,3]; verts_object / normal_object [S,T-start_t,O,3]; contact_object [S,O];
     contact_markers [S,143] -> (loss [S], state).  With ``full_verts`` [S,T,V,3] and ``full_ids`` = (rhand ids, 143
     marker ids) in the full mesh, ``body_verts`` may be a :class:`VertexPicker` gather and ``markers_143`` /
-    ``rhand_verts`` positions in it: the normals are then computed from ``full_verts``."""
+    ``rhand_verts`` positions in it: the normals are then computed from ``full_verts``.  ``picked`` (optional):
+    {'markers_143': [S,T,143,3], 'rhand': [S,T,n,3]} already picked out of ``body_verts`` (``VertexPicker.pick``)."""
     S, T = body_verts.shape[:2]
     n_frames = T if n_frames is None else n_frames            # the reference hard-codes 61
     n_tail = T - start_t
-    tail = body_verts[:, start_t:].reshape(S * n_tail, -1, 3)
     if full_verts is None:
         full_verts, full_ids = body_verts, (rhand_verts, markers_143)
     full_tail = full_verts[:, start_t:].reshape(S * n_tail, -1, 3)
@@ -56,13 +61,20 @@ def contact_loss_seq(bm, start_t, body_verts, markers_143, rhand_verts, contact_
     normals = vertex_normals_subset(bm, full_tail, sel)        # only the rows the loss reads, every frame, on the device
     n_rh = rhand_verts.shape[0]
     rh_normals_full, rh_normals = normals[:, :n_rh], normals[:, n_rh:]
-    body_markers = tail.index_select(1, markers_143)
-    rh_verts = tail.index_select(1, rhand_verts)
+    if picked is not None:
+        body_markers = picked['markers_143'][:, start_t:].reshape(S * n_tail, -1, 3)
+        rh_verts = picked['rhand'][:, start_t:].reshape(S * n_tail, -1, 3)
+    else:
+        tail = body_verts[:, start_t:].reshape(S * n_tail, -1, 3)
+        body_markers = tail.index_select(1, markers_143)
+        rh_verts = tail.index_select(1, rhand_verts)
     O = verts_object.shape[-2]
     vo, no = verts_object.float().reshape(S * n_tail, O, 3), normal_object.float().reshape(S * n_tail, O, 3)
-    _o2h_m, h2o_signed_marker, _, _, _o2h_vec, h2o_marker_vector = point2point_signed(body_markers, vo, None, no, return_vector=True)
+    # (the reference discards the object -> marker direction of this call, :154: it is not searched)
+    _o2h_m, h2o_signed_marker, _, _, _o2h_vec, h2o_marker_vector = point2point_signed(body_markers, vo, None, no, return_vector=True,
+                                                                                        directions='x2y')
     o2h_signed, h2o_signed, _, _ = point2point_signed(rh_verts, vo, rh_normals_full, no)
-    w = torch.zeros(n_frames - start_t, 1, device=tail.device)
+    w = torch.zeros(n_frames - start_t, 1, device=body_verts.device)
     w[-5:] = 1                                                 # attraction only over the last five frames (:163-165)
     seq = lambda t: t.reshape((S, n_tail) + t.shape[1:])
     o2h_signed, h2o_signed, h2o_signed_marker = seq(o2h_signed), seq(h2o_signed), seq(h2o_signed_marker)
@@ -81,15 +93,14 @@ def collision_loss_seq(state):
     return 5 * (o2h.abs() * mask).mean(dim=-1).mean(dim=-1)
 
 
-def skating_loss_seq(body_verts, contact_lbl_rec, groups, vel_thres=0.1):
+def skating_loss_seq(body_verts, contact_lbl_rec, groups, vel_thres=0.1, picked=None):
     """``skating_loss`` (:193-263): mean speed (30 fps) above ``vel_thres`` of the heel / toe vertices on the frames whose
     contact label is 1; a group with no such vertex contributes 0.  body_verts [S,T,V,3]; contact_lbl_rec [S,T,4] =
     (left heel, right heel, left toe, right toe)."""
     S = body_verts.shape[0]
     total = body_verts.new_zeros(S)
     for col, name in enumerate(['left_heel', 'right_heel', 'left_toe', 'right_toe']):
-        ids = groups[name].to(body_verts.device)
-        foot = body_verts.index_select(2, ids)
+        foot = picked[name] if picked is not None else body_verts.index_select(2, groups[name].to(body_verts.device))
         speed = ((foot[:, 1:] - foot[:, :-1]) * 30).norm(dim=-1)                        # [S, T-1, n]
         on = (contact_lbl_rec[:, :-1, col] == 1)[:, :, None] & (speed > vel_thres)
         cnt = on.sum(dim=(1, 2))
@@ -108,9 +119,9 @@ def angle_loss_seq(state, start_t, n_frames):
     return (mask[:, :, -22:] * (cos - 1) ** 2 * weight).mean(dim=(1, 2))
 
 
-def hand_smooth_loss_seq(body_verts, start_t, rhand_verts):
+def hand_smooth_loss_seq(body_verts, start_t, rhand_verts, picked=None):
     """``loss_rh_smooth`` (:386-387)."""
-    rh = body_verts[:, start_t:].index_select(2, rhand_verts)
+    rh = picked['rhand'][:, start_t:] if picked is not None else body_verts[:, start_t:].index_select(2, rhand_verts)
     return (rh[:, 1:] - rh[:, :-1]).norm(dim=-1).mean(dim=(1, 2))
 
 

@@ -284,6 +284,20 @@ def test_p2p_signed_operator_against_oracle_with_vectors_and_both_gradients():
     o = point2point_signed(xr, y.cuda(), xn.cuda(), yn.cuda())
     (o[0].sum() + o[1].sum()).backward()
     assert xr.grad is not None and len(o) == 4 and o[2].dtype == torch.int32
+    # directions='x2y': the y -> x search is skipped, its outputs are None, the x -> y outputs and their gradients are those of
+    # the full call with the y -> x outputs unused
+    res = {}
+    for d in ('both', 'x2y'):
+        xr, yr = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+        o = point2point_signed(xr, yr, None, yn.cuda(), return_vector=True, directions=d)
+        ((o[1] * w[1].cuda()).sum() + (o[5] * w[3].cuda()).sum()).backward()
+        res[d] = (o, xr.grad.clone(), yr.grad.clone())
+    assert res['x2y'][0][0] is None and res['x2y'][0][2] is None and res['x2y'][0][4] is None
+    for k in (1, 3, 5):
+        assert torch.equal(res['x2y'][0][k], res['both'][0][k])
+    assert torch.equal(res['x2y'][1], res['both'][1]) and torch.equal(res['x2y'][2], res['both'][2])
+    with pytest.raises(ValueError):
+        point2point_signed(x.cuda(), y.cuda(), directions='y2x')
 
 
 def test_point2point_signed_value_error():

@@ -84,6 +84,41 @@ def test_frames_as_batch_at_config4_size(body_model_dir):
     assert torch.equal(big.vertices[5 * T:6 * T], small.vertices) and torch.equal(big.joints[5 * T:6 * T], small.joints)
 
 
+def test_row_picker_matches_index_select():
+    """saga_pick_rows_fwd/bwd: overlapping and repeated sets out of one cloud == one index_select per set; the backward is
+    the sum of their index_add backwards (here exactly: every row is picked at most three times, sums of <= 3 terms in the
+    same order)."""
+    from saga_amd.geometry import RowPicker
+    g = torch.Generator().manual_seed(3)
+    U = 301
+    sets = {'a': torch.randperm(U, generator=g)[:79], 'b': torch.arange(40, 200), 'c': torch.tensor([5, 5, 7, 300, 0]), 'd': torch.arange(U)}
+    picker = RowPicker(sets, U)
+    src = torch.randn(3, 4, U, 3, generator=g).cuda().requires_grad_(True)
+    ref_src = src.detach().clone().requires_grad_(True)
+    out = picker(src)
+    wts = {k: torch.randn(3, 4, len(v), 3, generator=g).cuda() for k, v in sets.items()}
+    loss = sum((out[k] * wts[k]).sum() for k in sets)
+    loss_ref = 0
+    for k, v in sets.items():
+        ref = ref_src.index_select(2, v.cuda())
+        assert torch.equal(out[k], ref), k
+        loss_ref = loss_ref + (ref * wts[k]).sum()
+    loss.backward()
+    loss_ref.backward()
+    np.testing.assert_allclose(src.grad.cpu().numpy(), ref_src.grad.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    out2 = picker(src)
+    g2 = torch.autograd.grad(sum((out2[k] * wts[k]).sum() for k in sets), src)[0]
+    assert torch.equal(g2, src.grad)                                   # deterministic
+    pos, gall, exp = torch.cat(list(sets.values())), torch.cat([wts[k] for k in sets], dim=2), torch.zeros_like(g2)
+    for i in range(pos.numel()):                                       # the documented order: ascending pick position
+        exp[:, :, pos[i]] += gall[:, :, i]
+    assert torch.equal(g2, exp)
+    with pytest.raises(ValueError):
+        RowPicker({'x': torch.tensor([U])}, U)
+    with pytest.raises(ValueError):
+        picker(torch.zeros(2, U + 1, 3).cuda())
+
+
 # ---- the two-stage driver (MotionFill/models/fittingop.py:283-428), S sequences per launch ------------------------------
 def _fit_problem(body_model_dir, S, Tn, start_t, seed=0):
     """Targets from smooth synthetic motions: 79 markers per frame, an object next to the right hand of the last frame."""
