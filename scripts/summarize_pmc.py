@@ -16,7 +16,7 @@ import sys
 root = sys.argv[1]
 csv.field_size_limit(1 << 30)
 OURS = ('gemm_nt', 'skin_', 'pose_', 'joints_', 'grasp_loss', 'nn_scan', 'nn_fast', 'vertex_normals', 'cont6d', 'rodrigues',
-        'params_', 'loss_sum', 'adam_', 'best_update')
+        'params_', 'loss_sum', 'adam_', 'best_update', 'hand_ring', 'p2p_', 'pick_rows', 'nn_grad', 'da_sum')
 
 
 def short(name):
