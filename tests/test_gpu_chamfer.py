@@ -319,3 +319,28 @@ def test_vertex_normals_full_and_subset(body_model_dir):
     sel = torch.arange(7331, 7331 + 778, dtype=torch.int32).cuda()
     sub = vertex_normals_subset(bm, verts.cuda(), sel).cpu().numpy()
     assert_same(sub, full[:, 7331:7331 + 778])
+
+
+def test_vertex_normals_lds_staged_kernel_equals_gather_kernel(body_model_dir):
+    """Batches of >= 512 meshes take the kernel that stages each mesh in LDS first (saga_vertex_normals[_subset]); it must give
+    the gather kernel's bits (SAGA_NORMALS_GATHER=1 forces that one), for the subset and the full output, whatever the 16-B
+    alignment of a mesh's row (V * 3 = 31,425 floats: every alignment occurs)."""
+    import os
+    from saga_amd.geometry import vertex_normals, vertex_normals_subset
+    from tests.helpers import make_hip_model
+    bm = make_hip_model(body_model_dir, 1)
+    g = torch.Generator().manual_seed(5)
+    base = torch.randn(1, 10475, 3, generator=g).cuda()
+    verts = (base + 0.05 * torch.randn(515, 1, 3, generator=g).cuda()).contiguous()
+    verts[7] = 0.0                                  # degenerate faces: zero normals stay zero
+    sel = torch.cat([torch.arange(7331, 7331 + 778), torch.tensor([0, 10474, 5, 5])]).to(torch.int32).cuda()
+    got_sub, got_full = vertex_normals_subset(bm, verts, sel), vertex_normals(bm, verts)
+    os.environ['SAGA_NORMALS_GATHER'] = '1'
+    try:
+        ref_sub, ref_full = vertex_normals_subset(bm, verts, sel), vertex_normals(bm, verts)
+    finally:
+        del os.environ['SAGA_NORMALS_GATHER']
+    assert torch.equal(got_sub, ref_sub) and torch.equal(got_full, ref_full)
+    assert torch.equal(got_sub, got_full[:, sel.long()]) and got_full[7].abs().max() == 0
+    small = vertex_normals_subset(bm, verts[:4].contiguous(), sel)           # below the threshold: the gather kernel
+    assert torch.equal(small, got_sub[:4])
