@@ -181,16 +181,28 @@ int saga_p2p_signed_bwd(const float* x, const float* y, const int32_t* yidx, con
                         float* g_x, float* g_y, int N, int P1, int P2, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Row picks.  Replaces the per-set vertex gathers of the GraspMotion-Opt objective and their autograd backward
- * (MotionFill/models/fittingop.py:356-409: body_verts[:, markers], [:, rhand], [:, heel/toe ids] ...: one index_select per
- * set, each with a zero-filled full-size gradient and an index_add in the backward).
- *   saga_pick_rows_fwd : src [N,U,3], pos [P] (values in [0,U), repeats allowed) -> out [N,P,3] = src[:, pos]
- *   saga_pick_rows_bwd : g_out [N,P,3] -> g_src [N,U,3] (overwritten) = sum over the picks of each row, in ascending pick
- *                        order (inv_ptr [U+1], inv_idx [P]: CSR of pick positions per source row) -- deterministic
+ * Row picks.  Replaces the per-set vertex gathers and frame slices of the GraspMotion-Opt objective and their autograd
+ * backward (MotionFill/models/fittingop.py:356-409: body_verts[:, markers], body_verts[start_t:, rhand], heel / toe ids ...:
+ * one index_select (+ slice) per set, each with a zero-filled full-size gradient and an index_add in the backward).
+ *   src [S,T,U,3]; set k: pos [n] (values in [0,U), repeats allowed), t0 (first frame kept)
+ *   saga_pick_sets_fwd : out_k [S,T-t0,n,3] = src[:, t0:, pos]                      (every set in one launch)
+ *   saga_pick_sets_bwd : g_src [S,T,U,3] (overwritten) = sum over the sets (in order; a NULL g_out is skipped) and over
+ *                        the picks of each row in ascending pick order (inv_ptr [U+1], inv_idx [n]: CSR of pick positions
+ *                        per source row) -- deterministic, no atomics
+ * `sets` is a HOST array of n_sets <= SAGA_PICK_MAX_SETS descriptors whose pointers are device pointers.
  * ------------------------------------------------------------------------------------------ */
-int saga_pick_rows_fwd(const float* src, const int32_t* pos, float* out, int N, int U, int P, void* stream);
-int saga_pick_rows_bwd(const float* g_out, const int32_t* inv_ptr, const int32_t* inv_idx, float* g_src, int N, int U, int P,
-                       void* stream);
+#define SAGA_PICK_MAX_SETS 8
+typedef struct {
+    const int32_t* pos;       /* fwd */
+    const int32_t* inv_ptr;   /* bwd */
+    const int32_t* inv_idx;   /* bwd */
+    float* out;               /* fwd */
+    const float* g_out;       /* bwd (NULL: no gradient for this set) */
+    int32_t n;
+    int32_t t0;
+} saga_pick_set_t;
+int saga_pick_sets_fwd(const float* src, const saga_pick_set_t* sets, int n_sets, int S, int T, int U, void* stream);
+int saga_pick_sets_bwd(const saga_pick_set_t* sets, int n_sets, float* g_src, int S, int T, int U, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Vertex normals.  Replaces Open3D TriangleMesh.compute_vertex_normals()

@@ -46,6 +46,13 @@ class GraspTables(ctypes.Structure):
                 ('hand_tri_ptr', ctypes.c_void_p), ('hand_tri', ctypes.c_void_p)]
 
 
+class PickSet(ctypes.Structure):
+    """saga_pick_set_t"""
+    _fields_ = [('pos', ctypes.c_void_p), ('inv_ptr', ctypes.c_void_p), ('inv_idx', ctypes.c_void_p), ('out', ctypes.c_void_p),
+                ('g_out', ctypes.c_void_p), ('n', ctypes.c_int32), ('t0', ctypes.c_int32)]
+
+
+PICK_MAX_SETS = 8
 GRASP_NTERMS = 16
 
 # packed optimiser-variable row (include/saga_hip.h SAGA_VAR_*)
@@ -105,8 +112,8 @@ PROTOTYPES = {
                                            ctypes.c_int, c_stream]),
     'saga_p2p_signed_bwd': (ctypes.c_int, [c_float_p, c_float_p, c_int_p, c_int_p] + [c_float_p] * 8 + [ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, c_stream]),
-    'saga_pick_rows_fwd': (ctypes.c_int, [c_float_p, c_int_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
-    'saga_pick_rows_bwd': (ctypes.c_int, [c_float_p, c_int_p, c_int_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    'saga_pick_sets_fwd': (ctypes.c_int, [c_float_p, ctypes.POINTER(PickSet), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    'saga_pick_sets_bwd': (ctypes.c_int, [ctypes.POINTER(PickSet), ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
     'saga_vertex_normals': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_int, c_stream]),
     'saga_vertex_normals_subset': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_int_p, ctypes.c_int, c_float_p,
                                                   ctypes.c_int, c_stream]),

@@ -73,57 +73,73 @@ class _PickRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, picker):
         _lib.require_device(src)
-        lead, (U, D) = src.shape[:-2], src.shape[-2:]
-        if D != 3 or U != picker.n_rows:
-            raise ValueError('pick_rows: src must be [..., %d, 3], got %s' % (picker.n_rows, tuple(src.shape)))
+        if src.dim() < 3 or src.shape[-1] != 3 or src.shape[-2] != picker.n_rows:
+            raise ValueError('pick_rows: src must be [..., T, %d, 3], got %s' % (picker.n_rows, tuple(src.shape)))
         sc = src.detach().contiguous()
-        N = sc.numel() // (U * 3)
-        out = torch.empty(lead + (picker.n_picks, 3), device=sc.device, dtype=torch.float32)
-        pos, _, _ = picker.tables(sc.device)
-        _lib.call('saga_pick_rows_fwd', sc.device, _lib.ptr(sc), _lib.ptr(pos), _lib.ptr(out), N, U, picker.n_picks)
-        ctx.picker, ctx.src_shape = picker, src.shape
-        return out
+        T = sc.shape[-3] if sc.dim() >= 3 else 1
+        S = sc.numel() // (T * picker.n_rows * 3)
+        if max(picker.t0) >= T:
+            raise ValueError('pick_rows: a set starts at frame %d, src has %d frames' % (max(picker.t0), T))
+        lead = sc.shape[:-3]
+        outs = [torch.empty(lead + (T - t0, n, 3), device=sc.device, dtype=torch.float32) for n, t0 in zip(picker.sizes, picker.t0)]
+        tabs = picker.tables(sc.device)
+        sets = (_lib.PickSet * len(outs))(*[_lib.PickSet(pos=_lib.ptr(tb[0]), out=_lib.ptr(o), n=n, t0=t0)
+                                            for tb, o, n, t0 in zip(tabs, outs, picker.sizes, picker.t0)])
+        _lib.call('saga_pick_sets_fwd', sc.device, _lib.ptr(sc), sets, len(outs), S, T, picker.n_rows)
+        ctx.picker, ctx.src_shape, ctx.dims = picker, src.shape, (S, T)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *grads):
         picker = ctx.picker
-        g = g.contiguous()
-        gs = torch.empty(ctx.src_shape, device=g.device, dtype=torch.float32)
-        _, inv_ptr, inv_idx = picker.tables(g.device)
-        N = gs.numel() // (picker.n_rows * 3)
-        _lib.call('saga_pick_rows_bwd', g.device, _lib.ptr(g), _lib.ptr(inv_ptr), _lib.ptr(inv_idx), _lib.ptr(gs), N, picker.n_rows,
-                  picker.n_picks)
+        if all(g is None for g in grads):
+            return None, None
+        dev = next(g for g in grads if g is not None).device
+        grads = [None if g is None else g.contiguous() for g in grads]
+        gs = torch.empty(ctx.src_shape, device=dev, dtype=torch.float32)
+        tabs = picker.tables(dev)
+        sets = (_lib.PickSet * len(grads))(*[_lib.PickSet(inv_ptr=_lib.ptr(tb[1]), inv_idx=_lib.ptr(tb[2]), g_out=_lib.ptr(g), n=n, t0=t0)
+                                             for tb, g, n, t0 in zip(tabs, grads, picker.sizes, picker.t0)])
+        S, T = ctx.dims
+        _lib.call('saga_pick_sets_bwd', dev, sets, len(grads), _lib.ptr(gs), S, T, picker.n_rows)
         return gs, None
 
 
 class RowPicker:
-    """Several named row sets of one [..., U, 3] cloud picked by ONE kernel (``saga_pick_rows_fwd``) and differentiated by one
-    deterministic gather (``saga_pick_rows_bwd``).  ``sets``: {name: positions in [0, U)} (repeats and overlaps allowed).
-    ``picker(src)`` -> {name: [..., n, 3]} (views of one buffer; their gradients are concatenated, not zero-padded)."""
+    """Several named row sets of one [..., T, U, 3] cloud picked by ONE kernel (``saga_pick_sets_fwd``) and differentiated by
+    one deterministic gather (``saga_pick_sets_bwd``).  ``sets``: {name: positions in [0, U)} or {name: (positions, t0)} --
+    repeats and overlaps allowed; with ``t0`` the set is taken from frames t0.. of the T axis only.  ``picker(src)`` ->
+    {name: [..., T - t0, n, 3]} (contiguous tensors)."""
 
     def __init__(self, sets, n_rows):
         import numpy as np
+        if not 0 < len(sets) <= _lib.PICK_MAX_SETS:
+            raise ValueError('RowPicker: 1..%d sets' % _lib.PICK_MAX_SETS)
         self.names = list(sets)
-        self.sizes = [int(len(sets[k])) for k in self.names]
-        pos = np.concatenate([np.asarray(sets[k].cpu() if torch.is_tensor(sets[k]) else sets[k], dtype=np.int64).reshape(-1)
-                              for k in self.names])
-        if pos.size == 0 or pos.min() < 0 or pos.max() >= n_rows:
-            raise ValueError('RowPicker: positions must lie in [0, %d)' % n_rows)
-        self.n_rows, self.n_picks = int(n_rows), int(pos.size)
-        order = np.argsort(pos, kind='stable')                      # picks of a row in ascending pick order
-        ptr = np.zeros(n_rows + 1, dtype=np.int64)
-        np.add.at(ptr, pos + 1, 1)
-        self._host = (pos.astype(np.int32), np.cumsum(ptr).astype(np.int32), order.astype(np.int32))
+        self.n_rows = int(n_rows)
+        self.sizes, self.t0, self._host = [], [], []
+        for k in self.names:
+            v, t0 = sets[k] if isinstance(sets[k], tuple) else (sets[k], 0)
+            pos = np.asarray(v.cpu() if torch.is_tensor(v) else v, dtype=np.int64).reshape(-1)
+            if pos.size == 0 or pos.min() < 0 or pos.max() >= n_rows or t0 < 0:
+                raise ValueError('RowPicker: positions of %r must lie in [0, %d), t0 >= 0' % (k, n_rows))
+            order = np.argsort(pos, kind='stable')                      # picks of a row in ascending pick order
+            ptr = np.zeros(n_rows + 1, dtype=np.int64)
+            np.add.at(ptr, pos + 1, 1)
+            self.sizes.append(int(pos.size))
+            self.t0.append(int(t0))
+            self._host.append((pos.astype(np.int32), np.cumsum(ptr).astype(np.int32), order.astype(np.int32)))
         self._dev = {}
 
     def tables(self, device):
         t = self._dev.get(str(device))
         if t is None:
-            t = self._dev[str(device)] = tuple(torch.from_numpy(a).to(device) for a in self._host)
+            t = self._dev[str(device)] = [tuple(torch.from_numpy(a).to(device) for a in h) for h in self._host]
         return t
 
     def __call__(self, src):
-        return dict(zip(self.names, _PickRows.apply(src, self).split(self.sizes, dim=-2)))
+        return dict(zip(self.names, _PickRows.apply(src, self)))
 
 
 def vertex_normals(model, verts):

@@ -190,7 +190,10 @@ class FittingOP:
     def _make_picker(self, rhand_verts):
         sets = {'markers': self.markers_ids, 'markers_143': self.markers_ids_143, 'rhand': rhand_verts}
         sets.update(self.foot_groups)
-        self._picker = pk = ml.VertexPicker(sets, self.device)
+        # (the objective reads the 143 markers and the hand on the frames start_t.. only: picked as windows; the sets stay in
+        # the union, which is the gradient subset of the body model)
+        self._picker = pk = ml.VertexPicker(sets, self.device, windows={'markers_143_tail': ('markers_143', self.start_t),
+                                                                        'rhand_tail': ('rhand', self.start_t)})
         self._loss_model = None
         if not (self.sparse_backward and self.reduced_forward and self.body_smooth_loss is None):
             return

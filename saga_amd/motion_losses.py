@@ -29,12 +29,18 @@ class VertexPicker:
     result: the backward pass scatters into (and zero-fills, and accumulates) the full-size gradient once instead of
     once per set -- at 256 x 61 bodies each of those is a 2 GB round trip."""
 
-    def __init__(self, sets, device):
+    def __init__(self, sets, device, windows=None):
         ids = {k: torch.as_tensor(v, dtype=torch.long, device=device) for k, v in sets.items()}
         self.union = torch.unique(torch.cat(list(ids.values())))                       # sorted
         self.pos = {k: torch.searchsorted(self.union, v) for k, v in ids.items()}      # position of each id in the union
         self.ids = ids
-        self.rows = RowPicker(self.pos, int(self.union.shape[0]))      # every set out of the gathered union, one kernel
+        # every set out of the gathered union in one kernel; ``windows`` = {output name: (set name, first frame)} adds picks
+        # of a set on the frames first.. only (contiguous [S, T - first, n, 3]: what the contact terms read)
+        replaced = {src for src, _ in (windows or {}).values()}
+        picks = {k: v for k, v in self.pos.items() if k not in replaced}      # (a windowed set is not also picked on every frame)
+        for name, (src, t0) in (windows or {}).items():
+            picks[name] = (self.pos[src], int(t0))
+        self.rows = RowPicker(picks, int(self.union.shape[0]))
 
     def gather(self, body_verts):
         return body_verts.index_select(2, self.union)
@@ -62,8 +68,9 @@ def contact_loss_seq(bm, start_t, body_verts, markers_143, rhand_verts, contact_
     n_rh = rhand_verts.shape[0]
     rh_normals_full, rh_normals = normals[:, :n_rh], normals[:, n_rh:]
     if picked is not None:
-        body_markers = picked['markers_143'][:, start_t:].reshape(S * n_tail, -1, 3)
-        rh_verts = picked['rhand'][:, start_t:].reshape(S * n_tail, -1, 3)
+        tail = lambda k: picked[k + '_tail'] if k + '_tail' in picked else picked[k][:, start_t:]
+        body_markers = tail('markers_143').reshape(S * n_tail, -1, 3)
+        rh_verts = tail('rhand').reshape(S * n_tail, -1, 3)
     else:
         tail = body_verts[:, start_t:].reshape(S * n_tail, -1, 3)
         body_markers = tail.index_select(1, markers_143)
@@ -121,7 +128,10 @@ def angle_loss_seq(state, start_t, n_frames):
 
 def hand_smooth_loss_seq(body_verts, start_t, rhand_verts, picked=None):
     """``loss_rh_smooth`` (:386-387)."""
-    rh = picked['rhand'][:, start_t:] if picked is not None else body_verts[:, start_t:].index_select(2, rhand_verts)
+    if picked is not None:
+        rh = picked['rhand_tail'] if 'rhand_tail' in picked else picked['rhand'][:, start_t:]
+    else:
+        rh = body_verts[:, start_t:].index_select(2, rhand_verts)
     return (rh[:, 1:] - rh[:, :-1]).norm(dim=-1).mean(dim=(1, 2))
 
 

@@ -13,6 +13,6 @@ f=glob.glob('$OUT/**/*kernel_stats.csv',recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
 tot=sum(float(r['TotalDurationNs']) for r in rows)/1e6
 print('all kernels: %.1f ms' % tot)
-for r in rows[:24]:
+for r in rows[:44]:
     print('%8.2f ms %6s calls %9.1f us  %s' % (float(r['TotalDurationNs'])/1e6, r['Calls'], float(r['AverageNs'])/1e3, r['Name'][:90]))
 PY

@@ -85,23 +85,25 @@ def test_frames_as_batch_at_config4_size(body_model_dir):
 
 
 def test_row_picker_matches_index_select():
-    """saga_pick_rows_fwd/bwd: overlapping and repeated sets out of one cloud == one index_select per set; the backward is
-    the sum of their index_add backwards (here exactly: every row is picked at most three times, sums of <= 3 terms in the
-    same order)."""
+    """saga_pick_sets_fwd/bwd: overlapping and repeated sets out of one cloud, some on a window of the frame axis, == one
+    index_select (+ slice) per set; the backward is the sum of their backwards in the documented order (sets in order, picks of
+    a row in ascending position), bit for bit."""
     from saga_amd.geometry import RowPicker
     g = torch.Generator().manual_seed(3)
-    U = 301
-    sets = {'a': torch.randperm(U, generator=g)[:79], 'b': torch.arange(40, 200), 'c': torch.tensor([5, 5, 7, 300, 0]), 'd': torch.arange(U)}
+    U, S, T = 301, 3, 4
+    sets = {'a': torch.randperm(U, generator=g)[:79], 'b': (torch.arange(40, 200), 2), 'c': torch.tensor([5, 5, 7, 300, 0]),
+            'd': (torch.arange(U), 3)}
     picker = RowPicker(sets, U)
-    src = torch.randn(3, 4, U, 3, generator=g).cuda().requires_grad_(True)
+    src = torch.randn(S, T, U, 3, generator=g).cuda().requires_grad_(True)
     ref_src = src.detach().clone().requires_grad_(True)
     out = picker(src)
-    wts = {k: torch.randn(3, 4, len(v), 3, generator=g).cuda() for k, v in sets.items()}
+    plain = {k: (v if isinstance(v, tuple) else (v, 0)) for k, v in sets.items()}
+    wts = {k: torch.randn(S, T - t0, len(v), 3, generator=g).cuda() for k, (v, t0) in plain.items()}
     loss = sum((out[k] * wts[k]).sum() for k in sets)
     loss_ref = 0
-    for k, v in sets.items():
-        ref = ref_src.index_select(2, v.cuda())
-        assert torch.equal(out[k], ref), k
+    for k, (v, t0) in plain.items():
+        ref = ref_src[:, t0:].index_select(2, v.cuda())
+        assert out[k].is_contiguous() and torch.equal(out[k], ref), k
         loss_ref = loss_ref + (ref * wts[k]).sum()
     loss.backward()
     loss_ref.backward()
@@ -109,14 +111,23 @@ def test_row_picker_matches_index_select():
     out2 = picker(src)
     g2 = torch.autograd.grad(sum((out2[k] * wts[k]).sum() for k in sets), src)[0]
     assert torch.equal(g2, src.grad)                                   # deterministic
-    pos, gall, exp = torch.cat(list(sets.values())), torch.cat([wts[k] for k in sets], dim=2), torch.zeros_like(g2)
-    for i in range(pos.numel()):                                       # the documented order: ascending pick position
-        exp[:, :, pos[i]] += gall[:, :, i]
+    exp = torch.zeros_like(g2)
+    for k, (v, t0) in plain.items():                                   # the documented order
+        for i in range(len(v)):
+            exp[:, t0:, v[i]] += wts[k][:, :, i]
     assert torch.equal(g2, exp)
+    out3 = picker(src)                                                 # a set nobody differentiates gets no gradient work
+    g3 = torch.autograd.grad((out3['c'] * wts['c']).sum(), src)[0]
+    exp_c = torch.zeros_like(g3)
+    for i, v in enumerate(sets['c']):
+        exp_c[:, :, v] += wts['c'][:, :, i]
+    assert torch.equal(g3, exp_c)
     with pytest.raises(ValueError):
         RowPicker({'x': torch.tensor([U])}, U)
     with pytest.raises(ValueError):
-        picker(torch.zeros(2, U + 1, 3).cuda())
+        picker(torch.zeros(2, 4, U + 1, 3).cuda())
+    with pytest.raises(ValueError):
+        picker(torch.zeros(2, 3, U, 3).cuda())                        # set d starts at frame 3
 
 
 # ---- the two-stage driver (MotionFill/models/fittingop.py:283-428), S sequences per launch ------------------------------
