@@ -168,7 +168,9 @@ int saga_chamfer_bwd(const float* x, const float* y, const int32_t* idx1, const 
  * the nearest-neighbour search above, then x2y = x - y[xidx], y2x = y - x[yidx], their norms, and the sign of the dot product
  * with the OTHER cloud's normal at the neighbour (a NULL normal array leaves that direction unsigned; sign(0) = 0).
  *   y2x_signed [N,P2], x2y_signed [N,P1], yidx [N,P2], xidx [N,P1] int32; y2x_vec [N,P2,3] / x2y_vec [N,P1,3] optional (NULL).
- *   y2x_signed = yidx = y2x_vec = NULL: the y -> x direction is not searched (for callers that discard it, MotionFill :154).
+ *   y2x_signed = yidx = y2x_vec = NULL (or x2y_signed = xidx = x2y_vec = NULL): that direction is not searched -- for callers
+ *   that discard it (MotionFill/models/fittingop.py:154-158: the marker call's object -> marker outputs, the hand call's hand ->
+ *   object outputs).
  * Backward: gradients of the signed distances and / or of the difference vectors (each may be NULL) -> g_x [N,P1,3], g_y
  * [N,P2,3] (written; either may be NULL).  The reference's gather backward is a scatter-add with float atomics; here it is a
  * fixed-order gather: bit-reproducible.  A point that coincides with its neighbour gets no distance gradient (torch: NaN). */

@@ -256,23 +256,30 @@ extern "C" int saga_p2p_signed_fwd(const float* x, const float* y, const float* 
     SAGA_CHECK_ARG(N >= 0 && P1 >= 0 && P2 >= 0, "saga_p2p_signed_fwd: negative size");
     if (N == 0 || (P1 == 0 && P2 == 0)) return 0;
     SAGA_CHECK_ARG(P1 > 0 && P2 > 0, "saga_p2p_signed_fwd: empty cloud (P1=%d, P2=%d) has no nearest neighbour", P1, P2);
-    SAGA_CHECK_ARG(x && y && x2y_signed && xidx, "saga_p2p_signed_fwd: null argument");
-    // a caller that reads the x -> y direction only (the marker call of the GraspMotion-Opt contact loss discards the other,
-    // MotionFill/models/fittingop.py:154) passes y2x_signed = yidx = y2x_vec = NULL: that search is then not run
-    const bool both = y2x_signed != nullptr;
-    SAGA_CHECK_ARG(both ? yidx != nullptr : (yidx == nullptr && y2x_vec == nullptr),
+    SAGA_CHECK_ARG(x && y, "saga_p2p_signed_fwd: null argument");
+    // a caller that reads one direction only passes the other direction's outputs (signed, idx, vec) as NULL: that search is
+    // not run.  (GraspMotion-Opt discards the object -> marker direction of its marker call and never reads the hand -> object
+    // direction of its hand call: MotionFill/models/fittingop.py:154-158,178-190.)
+    const bool do_y2x = y2x_signed != nullptr, do_x2y = x2y_signed != nullptr;
+    SAGA_CHECK_ARG(do_y2x || do_x2y, "saga_p2p_signed_fwd: no direction requested");
+    SAGA_CHECK_ARG(do_y2x ? yidx != nullptr : (yidx == nullptr && y2x_vec == nullptr),
                    "saga_p2p_signed_fwd: y2x_signed, yidx (and y2x_vec) are given together or all NULL");
+    SAGA_CHECK_ARG(do_x2y ? xidx != nullptr : (xidx == nullptr && x2y_vec == nullptr),
+                   "saga_p2p_signed_fwd: x2y_signed, xidx (and x2y_vec) are given together or all NULL");
     SAGA_CHECK_ARG(N <= 65535, "saga_p2p_signed_fwd: batch %d exceeds 65535", N);
     hipStream_t st = (hipStream_t)stream;
     void* prof = saga_prof_begin(SAGA_PROF_CHAMFER, stream);
-    int rc = launch_scan(x, y, nullptr, xidx, N, P1, P2, st);
-    if (!rc && both) rc = launch_scan(y, x, nullptr, yidx, N, P2, P1, st);
+    int rc = 0;
+    if (do_x2y) rc = launch_scan(x, y, nullptr, xidx, N, P1, P2, st);
+    if (!rc && do_y2x) rc = launch_scan(y, x, nullptr, yidx, N, P2, P1, st);
     saga_prof_end(prof);
     if (rc) return rc;
     // x2y = x - y[xidx], signed by y_normals[xidx] (:76-81); y2x = y - x[yidx], signed by x_normals[yidx] (:68-74)
-    p2p_signed_kernel<<<(unsigned)(((size_t)N * P1 + 255) / 256), 256, 0, st>>>(x, y, y_normals, xidx, x2y_signed, x2y_vec, N, P1, P2);
-    SAGA_LAUNCH_CHECK();
-    if (both) {
+    if (do_x2y) {
+        p2p_signed_kernel<<<(unsigned)(((size_t)N * P1 + 255) / 256), 256, 0, st>>>(x, y, y_normals, xidx, x2y_signed, x2y_vec, N, P1, P2);
+        SAGA_LAUNCH_CHECK();
+    }
+    if (do_y2x) {
         p2p_signed_kernel<<<(unsigned)(((size_t)N * P2 + 255) / 256), 256, 0, st>>>(y, x, x_normals, yidx, y2x_signed, y2x_vec, N, P2, P1);
         SAGA_LAUNCH_CHECK();
     }
@@ -455,7 +462,9 @@ extern "C" int saga_p2p_signed_bwd(const float* x, const float* y, const int32_t
                                    void* stream) {
     SAGA_CHECK_ARG(N >= 0 && P1 >= 0 && P2 >= 0, "saga_p2p_signed_bwd: negative size");
     if (N == 0 || P1 == 0 || P2 == 0) return 0;
-    SAGA_CHECK_ARG(x && y && xidx && x2y_signed, "saga_p2p_signed_bwd: null argument");
+    SAGA_CHECK_ARG(x && y, "saga_p2p_signed_bwd: null argument");
+    SAGA_CHECK_ARG((xidx && x2y_signed) || (!g_x2y_signed && !g_x2y_vec),
+                   "saga_p2p_signed_bwd: gradients of the x -> y outputs need xidx and x2y_signed");
     SAGA_CHECK_ARG((yidx && y2x_signed) || (!g_y2x_signed && !g_y2x_vec),
                    "saga_p2p_signed_bwd: gradients of the y -> x outputs need yidx and y2x_signed");
     SAGA_CHECK_ARG(g_x || g_y, "saga_p2p_signed_bwd: no gradient requested");

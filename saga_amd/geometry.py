@@ -15,7 +15,7 @@ class _P2PSigned(torch.autograd.Function):
     norms + normal-dot signs forward; a deterministic (fixed-order gather, no atomics) backward to both clouds."""
 
     @staticmethod
-    def forward(ctx, x, y, x_normals, y_normals, want_vec, both=True):
+    def forward(ctx, x, y, x_normals, y_normals, want_vec, do_y2x=True, do_x2y=True):
         _lib.require_device(x, y, x_normals, y_normals)
         xc, yc = x.detach().contiguous(), y.detach().contiguous()
         xn = None if x_normals is None else x_normals.detach().contiguous()
@@ -23,10 +23,10 @@ class _P2PSigned(torch.autograd.Function):
         N, P1, _ = xc.shape
         P2 = yc.shape[1]
         f32, i32 = dict(device=xc.device, dtype=torch.float32), dict(device=xc.device, dtype=torch.int32)
-        y2x_s, x2y_s = (torch.empty(N, P2, **f32) if both else None), torch.empty(N, P1, **f32)
-        yidx, xidx = (torch.empty(N, P2, **i32) if both else None), torch.empty(N, P1, **i32)
-        y2x_v = torch.empty(N, P2, 3, **f32) if (want_vec and both) else None
-        x2y_v = torch.empty(N, P1, 3, **f32) if want_vec else None
+        y2x_s, x2y_s = (torch.empty(N, P2, **f32) if do_y2x else None), (torch.empty(N, P1, **f32) if do_x2y else None)
+        yidx, xidx = (torch.empty(N, P2, **i32) if do_y2x else None), (torch.empty(N, P1, **i32) if do_x2y else None)
+        y2x_v = torch.empty(N, P2, 3, **f32) if (want_vec and do_y2x) else None
+        x2y_v = torch.empty(N, P1, 3, **f32) if (want_vec and do_x2y) else None
         P = _lib.ptr
         _lib.call('saga_p2p_signed_fwd', xc.device, P(xc), P(yc), P(xn), P(yn), P(y2x_s), P(x2y_s), P(yidx), P(xidx), P(y2x_v),
                   P(x2y_v), N, P1, P2)
@@ -42,7 +42,7 @@ class _P2PSigned(torch.autograd.Function):
         xc, yc, yidx, xidx, y2x_s, x2y_s = ctx.saved_tensors
         need_x, need_y = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if not (need_x or need_y) or all(g is None for g in (g_y2x_s, g_x2y_s, g_y2x_v, g_x2y_v)):
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         c = lambda g: None if g is None else g.contiguous()
         gx = torch.empty_like(xc) if need_x else None
         gy = torch.empty_like(yc) if need_y else None
@@ -50,23 +50,23 @@ class _P2PSigned(torch.autograd.Function):
         P = _lib.ptr
         _lib.call('saga_p2p_signed_bwd', xc.device, P(xc), P(yc), P(yidx), P(xidx), P(y2x_s), P(x2y_s), P(c(g_y2x_s)), P(c(g_x2y_s)),
                   P(c(g_y2x_v)), P(c(g_x2y_v)), P(gx), P(gy), N, P1, yc.shape[1])
-        return gx, gy, None, None, None, None
+        return gx, gy, None, None, None, None, None
 
 
 def point2point_signed(x, y, x_normals=None, y_normals=None, return_vector=False, directions='both'):
     """Signed distance between two point clouds (``utils/train_helper.py:17-86``: same arguments, return order and
     ``ValueError``).  x [N,P1,3], y [N,P2,3] -> y2x_signed [N,P2], x2y_signed [N,P1], yidx_near [N,P2] int32,
     xidx_near [N,P1] int32 (, y2x [N,P2,3], x2y [N,P1,3]).  Differentiable w.r.t. ``x`` and ``y`` (not the normals: only
-    the sign of their dot product is used).  ``directions='x2y'`` (not in the reference): the y -> x search is not run and
-    its outputs (y2x_signed, yidx_near, y2x) are None -- for call sites that discard them."""
-    if directions not in ('both', 'x2y'):
-        raise ValueError("directions must be 'both' or 'x2y'")
+    the sign of their dot product is used).  ``directions='x2y'`` / ``'y2x'`` (not in the reference): the other direction's
+    search is not run and its outputs (signed distance, index, vector) are None -- for call sites that discard them."""
+    if directions not in ('both', 'x2y', 'y2x'):
+        raise ValueError("directions must be 'both', 'x2y' or 'y2x'")
     N, P1, D = x.shape
     if y.shape[0] != N or y.shape[2] != D:
         raise ValueError("y does not have the correct shape.")
     if D != 3:
         raise NotImplementedError('point2point_signed on the HIP path takes 3-D points (got D=%d)' % D)
-    return _P2PSigned.apply(x, y, x_normals, y_normals, bool(return_vector), directions == 'both')
+    return _P2PSigned.apply(x, y, x_normals, y_normals, bool(return_vector), directions != 'x2y', directions != 'y2x')
 
 
 class _PickRows(torch.autograd.Function):

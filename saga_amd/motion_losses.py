@@ -80,11 +80,13 @@ def contact_loss_seq(bm, start_t, body_verts, markers_143, rhand_verts, contact_
     # (the reference discards the object -> marker direction of this call, :154: it is not searched)
     _o2h_m, h2o_signed_marker, _, _, _o2h_vec, h2o_marker_vector = point2point_signed(body_markers, vo, None, no, return_vector=True,
                                                                                         directions='x2y')
-    o2h_signed, h2o_signed, _, _ = point2point_signed(rh_verts, vo, rh_normals_full, no)
+    # (no loss reads the hand -> object direction of this call -- h2o_signed_min :158 and mask_pulse_h2o :179-181 are dead code in
+    # the reference -- so it is not searched; state['h2o_signed'] is None)
+    o2h_signed, h2o_signed, _, _ = point2point_signed(rh_verts, vo, rh_normals_full, no, directions='y2x')
     w = torch.zeros(n_frames - start_t, 1, device=body_verts.device)
     w[-5:] = 1                                                 # attraction only over the last five frames (:163-165)
     seq = lambda t: t.reshape((S, n_tail) + t.shape[1:])
-    o2h_signed, h2o_signed, h2o_signed_marker = seq(o2h_signed), seq(h2o_signed), seq(h2o_signed_marker)
+    o2h_signed, h2o_signed_marker = seq(o2h_signed), seq(h2o_signed_marker)
     loss_obj = (o2h_signed.abs() * contact_object.reshape(S, 1, -1) * w).mean(dim=(1, 2))
     loss_mk = (h2o_signed_marker.abs() * contact_markers.reshape(S, 1, -1) * w).mean(dim=(1, 2))
     rh_normals = seq(rh_normals)

@@ -296,8 +296,18 @@ def test_p2p_signed_operator_against_oracle_with_vectors_and_both_gradients():
     for k in (1, 3, 5):
         assert torch.equal(res['x2y'][0][k], res['both'][0][k])
     assert torch.equal(res['x2y'][1], res['both'][1]) and torch.equal(res['x2y'][2], res['both'][2])
+    res = {}
+    for d in ('both', 'y2x'):
+        xr, yr = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+        o = point2point_signed(xr, yr, xn.cuda(), None, return_vector=True, directions=d)
+        ((o[0] * w[0].cuda()).sum() + (o[4] * w[2].cuda()).sum()).backward()
+        res[d] = (o, xr.grad.clone(), yr.grad.clone())
+    assert res['y2x'][0][1] is None and res['y2x'][0][3] is None and res['y2x'][0][5] is None
+    for k in (0, 2, 4):
+        assert torch.equal(res['y2x'][0][k], res['both'][0][k])
+    assert torch.equal(res['y2x'][1], res['both'][1]) and torch.equal(res['y2x'][2], res['both'][2])
     with pytest.raises(ValueError):
-        point2point_signed(x.cuda(), y.cuda(), directions='y2x')
+        point2point_signed(x.cuda(), y.cuda(), directions='neither')
 
 
 def test_point2point_signed_value_error():
