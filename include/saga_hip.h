@@ -207,14 +207,53 @@ int saga_pick_sets_fwd(const float* src, const saga_pick_set_t* sets, int n_sets
 int saga_pick_sets_bwd(const saga_pick_set_t* sets, int n_sets, float* g_src, int S, int T, int U, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The geometric terms of the GraspMotion-Opt stage-2 objective for S sequences of T frames as one operator.  Replaces the
+ * tensor expressions of MotionFill/models/fittingop.py:159-176 (contact), :178-191 (collision), :193-263 (skating), :265-280
+ * (hand angle), :360-368 (marker / end-pose fit), :386-387 (hand smoothness) and their autograd backward.
+ *   markers [S,T,M,3], markers_rec [S,T,M,3], marker_mask [M], markers_end [S,M,3]; feet [S,T,NF,3] = the four heel / toe
+ *   groups side by side in the column order of contact_lbl [S,T,4] (left heel, right heel, left toe, right toe);
+ *   hand_tail [S,n_tail,H,3]; o2h_signed [S,n_tail,O], h2o_marker [S,n_tail,CM], h2o_marker_vec [S,n_tail,CM,3] = outputs
+ *   of saga_p2p_signed_fwd; contact_object [S,O], contact_markers [S,CM]; palm_normals [S,n_tail,NP,3] (normals of the last
+ *   NP of the CM markers; no gradient).
+ *   terms [S,12]: rec_markers, end_markers_fit, skating, hand_smooth, contact, collision, hand_angle, 0, and the four
+ *   skating counts (read by the backward).   g_terms [S,7] -> gradients of the six differentiable inputs (each written whole).
+ * Fixed summation order: bit-reproducible, a sequence's terms do not depend on the batch.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t n_seq, n_frames, n_tail;       /* S, T, T - start_t */
+    int32_t n_markers;                     /* M (79) */
+    int32_t foot_group_size[4];            /* rows of `feet` per group, in contact_lbl column order */
+    int32_t n_hand, n_obj;                 /* H (778), O (2048) */
+    int32_t n_contact_markers, n_palm;     /* CM (143), NP (22) */
+    int32_t n_last_frames;                 /* frames at the end of the tail on which the contact term attracts (5, :163-165) */
+    float vel_thres;                       /* skating speed threshold (0.1) */
+} saga_motion_terms_cfg_t;
+#define SAGA_MOTION_NTERMS 12
+int saga_motion_terms_fwd(const saga_motion_terms_cfg_t* cfg, const float* markers, const float* markers_rec,
+                          const float* marker_mask, const float* markers_end, const float* feet, const float* contact_lbl,
+                          const float* hand_tail, const float* o2h_signed, const float* contact_object, const float* h2o_marker,
+                          const float* contact_markers, const float* h2o_marker_vec, const float* palm_normals, float* terms,
+                          void* stream);
+int saga_motion_terms_bwd(const saga_motion_terms_cfg_t* cfg, const float* markers, const float* markers_rec,
+                          const float* marker_mask, const float* markers_end, const float* feet, const float* contact_lbl,
+                          const float* hand_tail, const float* o2h_signed, const float* contact_object, const float* h2o_marker,
+                          const float* contact_markers, const float* h2o_marker_vec, const float* palm_normals, const float* terms,
+                          const float* g_terms, float* g_markers, float* g_feet, float* g_hand_tail, float* g_o2h_signed,
+                          float* g_h2o_marker, float* g_h2o_marker_vec, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Vertex normals.  Replaces Open3D TriangleMesh.compute_vertex_normals()
  * (WholeGraspPose/models/fittingop.py:158-164): area-weighted sum of face normals, normalised.
  *   saga_vertex_normals        : all vertices, verts [B,V,3] -> normals [B,V,3]
  *   saga_vertex_normals_subset : only the listed vertices (model's faces), -> [B,n_sel,3]
+ *   saga_vertex_normals_subset_window : verts [S,T,V,3], the listed vertices on the frames t0.. only -> [S,T-t0,n_sel,3]
+ *       (MotionFill/models/fittingop.py:137-146 computes the normals of the frames start_t.. only)
  * ------------------------------------------------------------------------------------------ */
 int saga_vertex_normals(const saga_model_t* m, const float* verts, float* normals, int B, void* stream);
 int saga_vertex_normals_subset(const saga_model_t* m, const float* verts, const int32_t* sel, int n_sel,
                                float* normals, int B, void* stream);
+int saga_vertex_normals_subset_window(const saga_model_t* m, const float* verts, const int32_t* sel, int n_sel, float* normals,
+                                      int S, int T, int t0, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused contact / penetration loss.  Replaces, for B independent candidates, everything

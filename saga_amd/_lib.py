@@ -53,6 +53,17 @@ class PickSet(ctypes.Structure):
 
 
 PICK_MAX_SETS = 8
+
+
+class MotionTermsCfg(ctypes.Structure):
+    """saga_motion_terms_cfg_t"""
+    _fields_ = [('n_seq', ctypes.c_int32), ('n_frames', ctypes.c_int32), ('n_tail', ctypes.c_int32), ('n_markers', ctypes.c_int32),
+                ('foot_group_size', ctypes.c_int32 * 4), ('n_hand', ctypes.c_int32), ('n_obj', ctypes.c_int32),
+                ('n_contact_markers', ctypes.c_int32), ('n_palm', ctypes.c_int32), ('n_last_frames', ctypes.c_int32),
+                ('vel_thres', ctypes.c_float)]
+
+
+MOTION_NTERMS = 12
 GRASP_NTERMS = 16
 
 # packed optimiser-variable row (include/saga_hip.h SAGA_VAR_*)
@@ -114,9 +125,13 @@ PROTOTYPES = {
                                            ctypes.c_int, c_stream]),
     'saga_pick_sets_fwd': (ctypes.c_int, [c_float_p, ctypes.POINTER(PickSet), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
     'saga_pick_sets_bwd': (ctypes.c_int, [ctypes.POINTER(PickSet), ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    'saga_motion_terms_fwd': (ctypes.c_int, [ctypes.POINTER(MotionTermsCfg)] + [c_float_p] * 14 + [c_stream]),
+    'saga_motion_terms_bwd': (ctypes.c_int, [ctypes.POINTER(MotionTermsCfg)] + [c_float_p] * 21 + [c_stream]),
     'saga_vertex_normals': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_int, c_stream]),
     'saga_vertex_normals_subset': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_int_p, ctypes.c_int, c_float_p,
                                                   ctypes.c_int, c_stream]),
+    'saga_vertex_normals_subset_window': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_int_p, ctypes.c_int, c_float_p,
+                                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
     'saga_grasp_loss_fwd': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(GraspTables)] + [ctypes.c_void_p] * 16 +
                             [ctypes.c_int, ctypes.c_int, c_stream]),
     'saga_grasp_loss_bwd': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(GraspTables)] + [ctypes.c_void_p] * 14 +

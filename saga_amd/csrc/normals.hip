@@ -14,13 +14,14 @@ void saga_prof_end(void* scope);
 
 __global__ void vertex_normals_kernel(const float* __restrict__ verts, const int32_t* __restrict__ vf_ptr,
                                       const int32_t* __restrict__ vf_tri, const int32_t* __restrict__ sel, int n_out,
-                                      float* __restrict__ normals, int V) {
+                                      float* __restrict__ normals, int V, int T, int t0) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (o >= n_out) return;
     const int v = sel ? sel[o] : o;
     float nx, ny, nz;
-    saga_vertex_normal(verts + (size_t)b * V * 3, vf_ptr, vf_tri, v, nx, ny, nz);
+    const int row = (b / (T - t0)) * T + t0 + b % (T - t0);       // output b = frame t0 + b % (T - t0) of sequence b / (T - t0)
+    saga_vertex_normal(verts + (size_t)row * V * 3, vf_ptr, vf_tri, v, nx, ny, nz);
     float* out = normals + ((size_t)b * n_out + o) * 3;
     out[0] = nx; out[1] = ny; out[2] = nz;
 }
@@ -32,10 +33,11 @@ __global__ void vertex_normals_kernel(const float* __restrict__ verts, const int
 #define VNL_THREADS 512
 __global__ __launch_bounds__(VNL_THREADS) void vertex_normals_lds_kernel(const float* __restrict__ verts, const int32_t* __restrict__ vf_ptr,
                                                                          const int32_t* __restrict__ vf_tri, const int32_t* __restrict__ sel,
-                                                                         int n_out, float* __restrict__ normals, int V) {
+                                                                         int n_out, float* __restrict__ normals, int V, int T, int t0) {
     extern __shared__ __attribute__((aligned(16))) float vnl_smem[];     // [3 + V*3]
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float* vb = verts + (size_t)b * V * 3;
+    const int row = (b / (T - t0)) * T + t0 + b % (T - t0);
+    const float* vb = verts + (size_t)row * V * 3;
     // the first output vertex's incidence range is requested before the row (model constants: L2)
     const int v_first = tid < n_out ? (sel ? sel[tid] : tid) : 0;
     const int e0_first = vf_ptr[v_first], e1_first = vf_ptr[v_first + 1];
@@ -72,7 +74,9 @@ __global__ __launch_bounds__(VNL_THREADS) void vertex_normals_lds_kernel(const f
     }
 }
 
-static int launch(const saga_model_t* m, const float* verts, const int32_t* sel, int n_out, float* normals, int B, void* stream) {
+// B outputs; T, t0: verts holds sequences of T meshes and output b is mesh t0 + b % (T - t0) of sequence b / (T - t0) (1, 0: mesh b)
+static int launch(const saga_model_t* m, const float* verts, const int32_t* sel, int n_out, float* normals, int B, int T, int t0,
+                  void* stream) {
     SAGA_CHECK_ARG(m && m->F > 0, "saga_vertex_normals: model has no faces");
     SAGA_CHECK_DEVICE(m, "saga_vertex_normals");
     SAGA_CHECK_ARG(B >= 0 && B <= 65535 && n_out >= 0, "saga_vertex_normals: bad sizes B=%d n=%d", B, n_out);
@@ -91,23 +95,31 @@ static int launch(const saga_model_t* m, const float* verts, const int32_t* sel,
     dim3 grid((n_out + 255) / 256, B);
     void* prof = saga_prof_begin(SAGA_PROF_NORMALS, stream);
     if (staged)
-        vertex_normals_lds_kernel<<<B, VNL_THREADS, lds, (hipStream_t)stream>>>(verts, m->vf_ptr, m->vf_tri, sel, n_out, normals, m->V);
+        vertex_normals_lds_kernel<<<B, VNL_THREADS, lds, (hipStream_t)stream>>>(verts, m->vf_ptr, m->vf_tri, sel, n_out, normals, m->V, T, t0);
     else
-        vertex_normals_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(verts, m->vf_ptr, m->vf_tri, sel, n_out, normals, m->V);
+        vertex_normals_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(verts, m->vf_ptr, m->vf_tri, sel, n_out, normals, m->V, T, t0);
     saga_prof_end(prof);
     SAGA_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int saga_vertex_normals(const saga_model_t* m, const float* verts, float* normals, int B, void* stream) {
-    return launch(m, verts, nullptr, m ? m->V : 0, normals, B, stream);
+    return launch(m, verts, nullptr, m ? m->V : 0, normals, B, 1, 0, stream);
 }
 
 // `sel` (device, int32) must hold vertex ids in [0, V): checked by the host wrapper that uploads it.
 extern "C" int saga_vertex_normals_subset(const saga_model_t* m, const float* verts, const int32_t* sel, int n_sel, float* normals,
                                           int B, void* stream) {
     SAGA_CHECK_ARG(sel || n_sel == 0, "saga_vertex_normals_subset: null selection");
-    return launch(m, verts, sel, n_sel, normals, B, stream);
+    return launch(m, verts, sel, n_sel, normals, B, 1, 0, stream);
+}
+
+// verts [S,T,V,3]: the listed vertices on the frames t0.. of every sequence only -> normals [S,T-t0,n_sel,3]
+extern "C" int saga_vertex_normals_subset_window(const saga_model_t* m, const float* verts, const int32_t* sel, int n_sel,
+                                                 float* normals, int S, int T, int t0, void* stream) {
+    SAGA_CHECK_ARG(sel || n_sel == 0, "saga_vertex_normals_subset_window: null selection");
+    SAGA_CHECK_ARG(S >= 0 && T > 0 && t0 >= 0 && t0 < T, "saga_vertex_normals_subset_window: bad sizes S=%d T=%d t0=%d", S, T, t0);
+    return launch(m, verts, sel, n_sel, normals, S * (T - t0), T, t0, stream);
 }
 
 // ---- the loss kernel's reads of the mesh, served once per candidate from LDS (saga_fit_step) --------------------------------

@@ -155,10 +155,19 @@ def vertex_normals(model, verts):
     return out
 
 
-def vertex_normals_subset(model, verts, sel):
-    """Normals of the listed vertices only: verts [B,V,3], sel int32 [n] (device) -> [B,n,3] (detached)."""
+def vertex_normals_subset(model, verts, sel, first_frame=None):
+    """Normals of the listed vertices only: verts [B,V,3], sel int32 [n] (device) -> [B,n,3] (detached).  With
+    ``first_frame`` = t0: verts [S,T,V,3] -> [S*(T-t0),n,3], the frames t0.. of every sequence (no copy of the slice)."""
     _lib.require_device(verts, sel)
     verts = verts.detach().contiguous()
+    if first_frame is not None:
+        S, T, V, _ = verts.shape
+        if V != model.num_verts or not 0 <= first_frame < T:
+            raise ValueError('verts has %d vertices (model: %d), first_frame %d of %d' % (V, model.num_verts, first_frame, T))
+        out = torch.empty(S * (T - first_frame), sel.shape[0], 3, device=verts.device, dtype=torch.float32)
+        _lib.call('saga_vertex_normals_subset_window', verts.device, model.handle(verts.device), _lib.ptr(verts), _lib.ptr(sel),
+                  sel.shape[0], _lib.ptr(out), S, T, int(first_frame))
+        return out
     B, V, _ = verts.shape
     if V != model.num_verts:
         raise ValueError('verts has %d vertices, the model %d' % (V, model.num_verts))

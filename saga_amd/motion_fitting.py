@@ -21,6 +21,7 @@ import torch.optim as optim
 from . import smplx as _smplx
 from . import motion_losses as ml
 from .fitting import load_grasp_indices
+from .geometry import point2point_signed, vertex_normals_subset
 from .rotations import cont6d_to_aa
 from .vposer import VPoserDecoder
 
@@ -76,12 +77,14 @@ class FittingOP:
     ``sparse_backward`` (default True: stage 2 differentiates through the vertices its losses read only -- same gradients up
     to summation order, no dense [S*T,V,3] gradient; switched off automatically with a ``body_smooth_loss`` hook, which may
     read any vertex), ``reduced_forward`` (default True, with ``sparse_backward``: stage 2 evaluates only the vertices its losses
-    and the hand normals read -- the same numbers, see ``_make_picker``)."""
+    and the hand normals read -- the same numbers, see ``_make_picker``), ``fused_terms`` (default True: the seven geometric
+    terms of stage 2 as one HIP operator, ``saga_motion_terms_fwd/bwd``; False: their autograd composition in
+    ``motion_losses``, the form the tests check it against)."""
 
     def __init__(self, fittingconfig):
         cfg = dict(T=61, gender='male', device='cuda', n_seq=1, start_t=30, init_lr_stage1=0.1, init_lr_stage2=0.01,
                    num_iter=[100, 300], body_model_path='./body_utils/body_models', vposer=None, smplx_kwargs={},
-                   indices=None, body_smooth_loss=None, sparse_backward=True, reduced_forward=True,
+                   indices=None, body_smooth_loss=None, sparse_backward=True, reduced_forward=True, fused_terms=True,
                    stage1_weight_loss_rec_markers=1.0, stage1_weight_loss_vposer=0.02, stage1_weight_loss_shape=0.01,
                    stage1_weight_loss_hand=0.01,
                    stage2_weight_loss_rec_markers=0.1, stage2_weight_loss_end_markers_fit=10, stage2_weight_loss_vposer=0.02,
@@ -242,6 +245,31 @@ class FittingOP:
             verts = verts.reshape(S, T, -1, 3)
             sub = pk.gather(verts)                               # every vertex any term reads, gathered once
         picked = pk.pick(sub)                                    # every set the terms read: one kernel, one backward gather
+        pp = p.reshape(S, T, -1)
+        if self.fused_terms:
+            # the seven geometric terms as one operator over the picks and the two nearest-neighbour calls (:154-157)
+            n_tail, O = T - start_t, verts_object.shape[-2]
+            cache = self.__dict__.setdefault('_fused_const', {})
+            if cache.get('key') != (id(pk), str(self.device)):
+                mask = torch.ones(picked['markers'].shape[2], device=self.device)      # (:360-364: hand, forearm, fingers out)
+                mask[49:49 + 6] = 0
+                mask[33:33 + 6] = 0
+                mask[69:] = 0
+                cache.update(key=(id(pk), str(self.device)), mask=mask,
+                             sel=torch.cat([normal_ids[0], normal_ids[1][-22:]]).to(torch.int32), n_rh=int(normal_ids[0].shape[0]))
+            normals = vertex_normals_subset(bm, verts, cache['sel'], first_frame=start_t)
+            vo, no = verts_object.float().reshape(S * n_tail, O, 3), normal_object.float().reshape(S * n_tail, O, 3)
+            _, h2o_mk, _, _, _, h2o_vec = point2point_signed(picked['markers_143_tail'].reshape(S * n_tail, -1, 3), vo, None, no,
+                                                             return_vector=True, directions='x2y')
+            o2h, _, _, _ = point2point_signed(picked['rhand_tail'].reshape(S * n_tail, -1, 3), vo, normals[:, :cache['n_rh']], no,
+                                              directions='y2x')
+            t7 = ml.motion_terms(picked['markers'], picked['feet'], pk.foot_sizes, picked['rhand_tail'], o2h, h2o_mk, h2o_vec,
+                                 markers_rec_T, cache['mask'], markers_end_new, contact_lbl_rec, contact_object, contact_markers,
+                                 normals[:, cache['n_rh']:])
+            terms = dict(zip(ml.TERM_NAMES, t7.unbind(1)))
+            terms['vposer'] = (pp[:, :, 16:48] ** 2).mean(dim=(1, 2))
+            terms['hand'] = (pp[:, :, 48:] ** 2).mean(dim=(1, 2))
+            return self._total(terms, verts, pp)
         markers = picked['markers']
         mask = torch.ones(1, 1, markers.shape[2], 1, device=self.device)
         mask[:, :, 49:49 + 6] = 0        # hand
@@ -257,9 +285,13 @@ class FittingOP:
         terms['hand_smooth'] = ml.hand_smooth_loss_seq(sub, start_t, pk.pos['rhand'], picked=picked)
         terms['collision'] = ml.collision_loss_seq(state)
         terms['hand_angle'] = ml.angle_loss_seq(state, start_t, T)
-        pp = p.reshape(S, T, -1)
         terms['vposer'] = (pp[:, :, 16:48] ** 2).mean(dim=(1, 2))
         terms['hand'] = (pp[:, :, 48:] ** 2).mean(dim=(1, 2))
+        return self._total(terms, verts, pp)
+
+    def _total(self, terms, verts, pp):
+        """Weighted sum of the stage-2 terms (``:391-409``) -> (total [S], terms)."""
+        w = self
         total = (w.stage2_weight_loss_rec_markers * terms['rec_markers']
                  + w.stage2_weight_loss_end_markers_fit * terms['end_markers_fit']
                  + w.stage2_weight_loss_vposer * terms['vposer']

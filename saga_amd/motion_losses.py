@@ -9,8 +9,11 @@ the gradient of its own B=1 problem); the un-suffixed form takes one sequence ``
 argument order and returns the reference's scalar.  The learned smoothness prior (``body_smooth_loss`` ``:70-130``: a
 convolutional auto-encoder) is a network, not part of this path.
 """
+import ctypes
+
 import torch
 
+from . import _lib
 from .geometry import RowPicker, point2point_signed, vertex_normals_subset
 
 
@@ -38,6 +41,10 @@ class VertexPicker:
         # of a set on the frames first.. only (contiguous [S, T - first, n, 3]: what the contact terms read)
         replaced = {src for src, _ in (windows or {}).values()}
         picks = {k: v for k, v in self.pos.items() if k not in replaced}      # (a windowed set is not also picked on every frame)
+        self.foot_sizes = None
+        if all(k in picks for k in FOOT_ORDER):                               # the heel / toe groups side by side, one pick
+            self.foot_sizes = [int(picks[k].shape[0]) for k in FOOT_ORDER]
+            picks['feet'] = torch.cat([picks.pop(k) for k in FOOT_ORDER])
         for name, (src, t0) in (windows or {}).items():
             picks[name] = (self.pos[src], int(t0))
         self.rows = RowPicker(picks, int(self.union.shape[0]))
@@ -47,7 +54,10 @@ class VertexPicker:
 
     def pick(self, union_verts):
         """{set name: [S,T,n,3]} out of ``gather``'s result (one kernel forward, one deterministic gather backward)."""
-        return self.rows(union_verts)
+        out = self.rows(union_verts)
+        if self.foot_sizes is not None:
+            out.update(zip(FOOT_ORDER, out['feet'].split(self.foot_sizes, dim=-2)))
+        return out
 
 
 def contact_loss_seq(bm, start_t, body_verts, markers_143, rhand_verts, contact_object, contact_markers, normal_object,
@@ -62,9 +72,8 @@ def contact_loss_seq(bm, start_t, body_verts, markers_143, rhand_verts, contact_
     n_tail = T - start_t
     if full_verts is None:
         full_verts, full_ids = body_verts, (rhand_verts, markers_143)
-    full_tail = full_verts[:, start_t:].reshape(S * n_tail, -1, 3)
     sel = torch.cat([full_ids[0], full_ids[1][-22:]]).to(torch.int32)          # right hand + its 22 palm markers (:133)
-    normals = vertex_normals_subset(bm, full_tail, sel)        # only the rows the loss reads, every frame, on the device
+    normals = vertex_normals_subset(bm, full_verts, sel, first_frame=start_t)   # only the rows the loss reads, frames start_t..
     n_rh = rhand_verts.shape[0]
     rh_normals_full, rh_normals = normals[:, :n_rh], normals[:, n_rh:]
     if picked is not None:
@@ -135,6 +144,63 @@ def hand_smooth_loss_seq(body_verts, start_t, rhand_verts, picked=None):
     else:
         rh = body_verts[:, start_t:].index_select(2, rhand_verts)
     return (rh[:, 1:] - rh[:, :-1]).norm(dim=-1).mean(dim=(1, 2))
+
+
+# ---- the same terms as ONE operator (saga_motion_terms_fwd/bwd) -------------------------------------------------------------
+TERM_NAMES = ('rec_markers', 'end_markers_fit', 'skating', 'hand_smooth', 'contact', 'collision', 'hand_angle')
+FOOT_ORDER = ('left_heel', 'right_heel', 'left_toe', 'right_toe')          # the columns of contact_lbl_rec (:218-258)
+
+
+class _MotionTerms(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, markers, feet, hand_tail, o2h_signed, h2o_marker, h2o_marker_vec, markers_rec, marker_mask,
+                markers_end, contact_lbl, contact_object, contact_markers, palm_normals):
+        args = [markers, markers_rec, marker_mask, markers_end, feet, contact_lbl, hand_tail, o2h_signed, contact_object,
+                h2o_marker, contact_markers, h2o_marker_vec, palm_normals]
+        _lib.require_device(*args)
+        args = [a.detach().contiguous().float() for a in args]
+        S = cfg.n_seq
+        expect = [(S, cfg.n_frames, cfg.n_markers, 3), (S, cfg.n_frames, cfg.n_markers, 3), (cfg.n_markers,), (S, cfg.n_markers, 3),
+                  (S, cfg.n_frames, sum(cfg.foot_group_size), 3), (S, cfg.n_frames, 4), (S, cfg.n_tail, cfg.n_hand, 3),
+                  (S * cfg.n_tail * cfg.n_obj,), (S, cfg.n_obj), (S * cfg.n_tail * cfg.n_contact_markers,), (S, cfg.n_contact_markers),
+                  (S * cfg.n_tail * cfg.n_contact_markers * 3,), (S * cfg.n_tail * cfg.n_palm * 3,)]
+        for i, (a, e) in enumerate(zip(args, expect)):
+            n = 1
+            for x in e:
+                n *= x
+            if a.numel() != n:
+                raise ValueError('motion_terms: argument %d has shape %s, expected %s' % (i, tuple(a.shape), e))
+        terms = torch.empty(S, _lib.MOTION_NTERMS, device=args[0].device, dtype=torch.float32)
+        _lib.call('saga_motion_terms_fwd', terms.device, ctypes.byref(cfg), *[_lib.ptr(a) for a in args], _lib.ptr(terms))
+        ctx.cfg = cfg
+        ctx.save_for_backward(terms, *args)
+        ctx.shapes = [t.shape for t in (markers, feet, hand_tail, o2h_signed, h2o_marker, h2o_marker_vec)]
+        return terms[:, :7].clone()
+
+    @staticmethod
+    def backward(ctx, g_terms):
+        terms, *args = ctx.saved_tensors
+        f32 = dict(device=terms.device, dtype=torch.float32)
+        outs = [torch.empty(s, **f32) for s in ctx.shapes]
+        g = g_terms.contiguous().float()
+        _lib.call('saga_motion_terms_bwd', terms.device, ctypes.byref(ctx.cfg), *[_lib.ptr(a) for a in args], _lib.ptr(terms), _lib.ptr(g),
+                  *[_lib.ptr(o) for o in outs])
+        return (None,) + tuple(outs) + (None,) * 7
+
+
+def motion_terms(markers, feet, foot_sizes, hand_tail, o2h_signed, h2o_marker, h2o_marker_vec, markers_rec, marker_mask,
+                 markers_end, contact_lbl, contact_object, contact_markers, palm_normals, vel_thres=0.1, n_last_frames=5):
+    """The seven geometric stage-2 terms per sequence -> [S,7] in ``TERM_NAMES`` order.  markers [S,T,M,3]; feet [S,T,NF,3] =
+    the four groups of ``FOOT_ORDER`` side by side (``foot_sizes``); hand_tail [S,n_tail,H,3]; o2h_signed [S*n_tail,O],
+    h2o_marker [S*n_tail,CM], h2o_marker_vec [S*n_tail,CM,3] as ``point2point_signed`` returns them; palm_normals
+    [S*n_tail,NP,3].  Differentiable w.r.t. the first six tensors."""
+    S, T, M, _ = markers.shape
+    n_tail, H = hand_tail.shape[1], hand_tail.shape[2]
+    cfg = _lib.MotionTermsCfg(n_seq=S, n_frames=T, n_tail=n_tail, n_markers=M, foot_group_size=(ctypes.c_int32 * 4)(*foot_sizes),
+                              n_hand=H, n_obj=contact_object.shape[-1], n_contact_markers=contact_markers.shape[-1],
+                              n_palm=palm_normals.shape[-2], n_last_frames=n_last_frames, vel_thres=vel_thres)
+    return _MotionTerms.apply(cfg, markers, feet, hand_tail, o2h_signed, h2o_marker, h2o_marker_vec, markers_rec, marker_mask,
+                              markers_end, contact_lbl, contact_object, contact_markers, palm_normals)
 
 
 # ---- one sequence, the reference's argument order and scalar results ------------------------------------------------------

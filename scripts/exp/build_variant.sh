@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../../saga_amd/csrc"
 OUT=../../build/variants; OBJ=../../build/obj_$NAME
 mkdir -p $OUT $OBJ
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=fast-honor-pragmas $*"
-for f in model pose blend_gemm skin chamfer normals smplx_api grasp_loss rot6d fit_step rows; do
+for f in model pose blend_gemm skin chamfer normals smplx_api grasp_loss rot6d fit_step rows motion_terms; do
   /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $OBJ/$f.o &
 done
 wait

@@ -272,6 +272,52 @@ def test_motion_stage2_sparse_backward_matches_dense(body_model_dir, mesh_model_
         assert torch.equal(a, b)
 
 
+def test_motion_fused_terms_match_composition(body_model_dir):
+    """saga_motion_terms_fwd/bwd (the seven geometric stage-2 terms as one operator) against their autograd composition in
+    motion_losses (itself checked against the oracle above): every term within 2e-6 relative (float32 sums in another order),
+    gradients of the optimisation variables within 1e-4, run-to-run bit-equal; skating / contact / collision / angle active."""
+    S, Tn, start_t = 2, 13, 6
+    idx, _, vposer, prob = _fit_problem(body_model_dir, S, Tn, start_t, seed=20)
+    g = torch.Generator().manual_seed(9)
+    lam = torch.linspace(0, 1, Tn)[None, :, None]
+    transl = torch.tensor([0.0, 0.4, 1.0]) + 0.02 * lam + 0.002 * torch.randn(S, Tn, 3, generator=g)
+    rot6 = torch.tensor([-1., 0, 0, 0, 0, 1]).expand(S, Tn, 6) + 0.05 * torch.randn(S, Tn, 6, generator=g)
+    other = 0.1 * torch.randn(S, 1, 80, generator=g) + 0.05 * lam * torch.randn(S, 1, 80, generator=g)
+    shape = prob['beta'][:, None].expand(S, Tn, 10).float().contiguous()
+    f = lambda a, *sh: torch.as_tensor(a).cuda().float().reshape(*sh)
+    rh = torch.as_tensor(idx['rhand'], dtype=torch.long, device='cuda')
+    vo = f(prob['vo'], S, Tn - start_t, 2048, 3).clone()
+    res = {}
+    for mode in ('composition', 'fused', 'fused again'):
+        op = _hip_op(body_model_dir, idx, vposer, prob, S, Tn, start_t, [0, 1])
+        op.fused_terms = mode != 'composition'
+        op.init_param_T(transl, rot6, other, shape.numpy())
+        if mode == 'composition':      # object points 4-7 mm from the palm markers of the last frames: the angle term is active
+            from saga_amd.motion_fitting import convert_to_3D_rot, gen_body_mesh_v1
+            with torch.no_grad():
+                p = convert_to_3D_rot(torch.cat([op.transl_opt_T, op.rot_6d_opt_T, op.shape_T, op.other_params_opt_T], -1).reshape(S * Tn, -1))
+                v = gen_body_mesh_v1(p, op.smplx_model_batch, op.vposer_model)[0].reshape(S, Tn, -1, 3)
+                vo[:, :, :22] = v[:, start_t:, op.markers_ids_143[-22:]] + 0.004
+        total, terms = op.stage2_losses(f(prob['markers_rec'], S, Tn, -1, 3), f(prob['markers_end'], S, -1, 3), rh,
+                                        f(prob['lbl'], S, Tn, 4), f(prob['c_obj'], S, -1), f(prob['c_mk'], S, -1),
+                                        f(prob['no'], S, Tn - start_t, 2048, 3), vo)
+        total.sum().backward()
+        res[mode] = (total.detach(), {k: v.detach() for k, v in terms.items()},
+                     [t.grad.clone() for t in (op.transl_opt_T, op.rot_6d_opt_T, op.other_params_opt_T)])
+    ref, got = res['composition'], res['fused']
+    assert set(ref[1]) == set(got[1])
+    for k in ref[1]:
+        np.testing.assert_allclose(got[1][k].cpu().numpy(), ref[1][k].cpu().numpy(), rtol=2e-6, atol=1e-9, err_msg=k)
+    for k in ('skating', 'contact', 'collision', 'hand_angle', 'hand_smooth'):
+        assert (ref[1][k] > 0).all(), k
+    np.testing.assert_allclose(got[0].cpu().numpy(), ref[0].cpu().numpy(), rtol=2e-6)
+    for a, b in zip(got[2], ref[2]):
+        assert b.abs().max() > 0 and rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-4
+    assert torch.equal(res['fused again'][0], got[0])
+    for a, b in zip(res['fused again'][2], got[2]):
+        assert torch.equal(a, b)
+
+
 def test_motion_fitting_sequences_are_independent(body_model_dir):
     """The batched driver gives each sequence the result of its own run: S = 2 equals two S = 1 runs up to the rounding
     of the torch / rocBLAS pieces whose reduction order depends on the batch shape (VPoser linears, means)."""
