@@ -12,8 +12,12 @@
 #define FEAT_K SAGA_FEAT_K      // 512
 #define DA_ROWS 56              // 55 joints + 1 all-ones row (sum of gradients -> d transl)
 #define DS_THREADS 256          // sparse dA reduction: lanes (= items) per block
+#ifndef DS_VR
 #define DS_VR 1024              // ... and the most vertices a block stages in LDS (6 floats each: 42 KB)
+#endif
+#ifndef DS_MAX_PARTS
 #define DS_MAX_PARTS 16         // partial sums live in the split-K slab space: parts * SAGA_DA_STRIDE <= 16 * 512 floats per candidate
+#endif
 #define DS_MAX_CHUNK 64         // longer chunks mean the weights are dense: the MFMA reduction takes over
 #define WT_COLS 64              // dense weight table padded to 64 columns for the MFMA dA reduction
 
