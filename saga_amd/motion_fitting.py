@@ -79,12 +79,13 @@ class FittingOP:
     read any vertex), ``reduced_forward`` (default True, with ``sparse_backward``: stage 2 evaluates only the vertices its losses
     and the hand normals read -- the same numbers, see ``_make_picker``), ``fused_terms`` (default True: the seven geometric
     terms of stage 2 as one HIP operator, ``saga_motion_terms_fwd/bwd``; False: their autograd composition in
-    ``motion_losses``, the form the tests check it against)."""
+    ``motion_losses``, the form the tests check it against), ``graph_stage1`` (default True: stage 1 replays one captured
+    iteration, see ``fitting_stage1``)."""
 
     def __init__(self, fittingconfig):
         cfg = dict(T=61, gender='male', device='cuda', n_seq=1, start_t=30, init_lr_stage1=0.1, init_lr_stage2=0.01,
                    num_iter=[100, 300], body_model_path='./body_utils/body_models', vposer=None, smplx_kwargs={},
-                   indices=None, body_smooth_loss=None, sparse_backward=True, reduced_forward=True, fused_terms=True,
+                   indices=None, body_smooth_loss=None, sparse_backward=True, reduced_forward=True, fused_terms=True, graph_stage1=True,
                    stage1_weight_loss_rec_markers=1.0, stage1_weight_loss_vposer=0.02, stage1_weight_loss_shape=0.01,
                    stage1_weight_loss_hand=0.01,
                    stage2_weight_loss_rec_markers=0.1, stage2_weight_loss_end_markers_fit=10, stage2_weight_loss_vposer=0.02,
@@ -154,34 +155,87 @@ class FittingOP:
             group['lr'] = lr
 
     # ---- stage 1 -------------------------------------------------------------------------------------------------------
+    def _stage1_model(self):
+        """Stage 1 reads the 79 markers only: the body model over those vertices (rows bit-identical to the full mesh's)."""
+        if self.__dict__.get('_s1_model') is None:
+            ids = self.markers_ids.cpu().numpy()
+            keep = np.unique(ids)
+            self._s1_model = (self._make_body_model(self.n_seq, vertex_subset=keep),
+                              torch.as_tensor(np.searchsorted(keep, ids), dtype=torch.long, device=self.device))
+        return self._s1_model
+
+    def _stage1_iteration(self, markers_rec_t):
+        """One Adam iteration of the per-frame marker fit (``:300-331``)."""
+        w = self
+        self.optimizer_s1.zero_grad(set_to_none=True)
+        p = convert_to_3D_rot(torch.cat([self.transl_opt_t, self.rot_6d_opt_t, self.shape_t, self.other_params_opt_t], dim=-1))
+        if self.reduced_forward:
+            bm, pos = self._stage1_model()
+            markers = gen_body_mesh_v1(p, bm, self.vposer_model)[0].index_select(1, pos)
+        else:
+            markers = gen_body_mesh_v1(p, self.smplx_model, self.vposer_model)[0].index_select(1, self.markers_ids)
+        loss_marker = (markers - markers_rec_t).abs().mean(dim=(1, 2))
+        loss = (w.stage1_weight_loss_rec_markers * loss_marker
+                + w.stage1_weight_loss_vposer * (p[:, 16:48] ** 2).mean(dim=1)
+                + w.stage1_weight_loss_shape * (p[:, 6:16] ** 2).mean(dim=1)
+                + w.stage1_weight_loss_hand * (p[:, 48:] ** 2).mean(dim=1))
+        loss.sum().backward()
+        self.optimizer_s1.step()
+
     def fitting_stage1(self, body_markers_rec):
         """``:283-340``.  body_markers_rec [S,T,79,3] (or [T,79,3] when S = 1) -> transl [S,T,3], rot6d [S,T,6],
-        shape [S,T,10], other [S,T,80], markers [S,T,79,3]."""
+        shape [S,T,10], other [S,T,80], markers [S,T,79,3].
+
+        The T x num_iter[0] iterations are small (S bodies, 79 vertices) and launch-bound -- ~150 launches of a few microseconds
+        each -- so with ``graph_stage1`` (default) ONE iteration is captured in a HIP graph (``torch.cuda.CUDAGraph``; the
+        library's operators enqueue on the capturing stream and allocate nothing) and replayed: the frame's targets and the
+        learning rate are device tensors the graph reads."""
         S, T = self.n_seq, self.T
         rec = torch.as_tensor(body_markers_rec).to(self.device).float().reshape(S, T, -1, 3)
-        self.optimizer_s1 = optim.Adam([self.transl_opt_t, self.rot_6d_opt_t, self.other_params_opt_t], lr=self.init_lr_stage1)
+        params = [self.transl_opt_t, self.rot_6d_opt_t, self.other_params_opt_t]
+        graph = bool(self.graph_stage1) and self.num_iter[0] > 0 and T > 0
+        if graph:
+            lr = torch.tensor(float(self.init_lr_stage1), device=self.device)
+            self.optimizer_s1 = optim.Adam(params, lr=lr, capturable=True)
+            target = rec[:, 0].clone()
+            # warm-up off the capture (lazy handles, autotuning, allocator), then put variables and Adam state back
+            keep = [q.detach().clone() for q in params]
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._stage1_iteration(target)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            with torch.no_grad():
+                for q, k in zip(params, keep):
+                    q.copy_(k)
+                for st in self.optimizer_s1.state.values():
+                    st['step'].zero_(); st['exp_avg'].zero_(); st['exp_avg_sq'].zero_()
+            self.optimizer_s1.zero_grad(set_to_none=True)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._stage1_iteration(target)
+            set_lr = lambda v: lr.fill_(v)
+            run = g.replay
+        else:
+            self.optimizer_s1 = optim.Adam(params, lr=self.init_lr_stage1)
+            target = None
+            set_lr = lambda v: self._set_lr(self.optimizer_s1, v)
         out = {k: [] for k in ('transl', 'rot', 'shape', 'other')}
-        w = self
         for t in range(T):
-            markers_rec_t = rec[:, t]
+            if graph:
+                target.copy_(rec[:, t])
+            else:
+                markers_rec_t = rec[:, t]
+                run = lambda: self._stage1_iteration(markers_rec_t)
             if t > 0:
-                self._set_lr(self.optimizer_s1, 0.005)
+                set_lr(0.005)
             for step in range(self.num_iter[0]):
-                if step > 60:
-                    self._set_lr(self.optimizer_s1, 0.01)
-                if step > 80:
-                    self._set_lr(self.optimizer_s1, 0.003)
-                self.optimizer_s1.zero_grad()
-                p = convert_to_3D_rot(torch.cat([self.transl_opt_t, self.rot_6d_opt_t, self.shape_t, self.other_params_opt_t], dim=-1))
-                verts, _ = gen_body_mesh_v1(p, self.smplx_model, self.vposer_model)
-                markers = verts.index_select(1, self.markers_ids)
-                loss_marker = (markers - markers_rec_t).abs().mean(dim=(1, 2))
-                loss = (w.stage1_weight_loss_rec_markers * loss_marker
-                        + w.stage1_weight_loss_vposer * (p[:, 16:48] ** 2).mean(dim=1)
-                        + w.stage1_weight_loss_shape * (p[:, 6:16] ** 2).mean(dim=1)
-                        + w.stage1_weight_loss_hand * (p[:, 48:] ** 2).mean(dim=1))
-                loss.sum().backward()
-                self.optimizer_s1.step()
+                if step == 61:
+                    set_lr(0.01)
+                if step == 81:
+                    set_lr(0.003)
+                run()
             out['transl'].append(self.transl_opt_t.detach().clone())
             out['rot'].append(self.rot_6d_opt_t.detach().clone())
             out['shape'].append(self.shape_t.detach().clone())
