@@ -378,6 +378,12 @@ typedef struct {
     int32_t skip_gated_terms; /* 1: in a stage whose contact / collision weights are all zero (stage < 2, or only_rec) those terms
                                  and the four counts are not evaluated and come back as 0 (the reference evaluates and logs them
                                  although they do not reach the loss, fittingop.py:215-242); 0: the reference's behaviour */
+    int32_t custom_weights; /* 0: the GraspPose-Opt objective of fittingop.py:215-223.  1: a marker-fit objective with the
+                               weights below -- total = w_rec * rec + reg_vpose * mean(vpose^2) + reg_shape * mean(betas^2) +
+                               reg_hand * mean(hand^2) + w_foot * foot + reg_eye * mean(eye^2) -- which is stage 1 of
+                               GraspMotion-Opt (MotionFill/models/fittingop.py:309-325: 1, 0.02, 0.01, 0.01, 0, 0) when the
+                               tables list its 79 markers; needs stage = 0 and skip_gated_terms = 1 */
+    float w_rec, w_foot, reg_vpose, reg_hand, reg_eye, reg_shape;
 } saga_fit_step_cfg_t;
 
 /* floats of workspace saga_fit_step / saga_fit_decode need for B candidates and O object points */

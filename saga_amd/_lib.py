@@ -95,7 +95,9 @@ class FitStepCfg(ctypes.Structure):
     _fields_ = [('stage', ctypes.c_int32), ('only_rec', ctypes.c_int32), ('prior_contact', ctypes.c_int32),
                 ('update_mask', ctypes.c_int32), ('adam_step', ctypes.c_int32),
                 ('lr', ctypes.c_float), ('beta1', ctypes.c_float), ('beta2', ctypes.c_float), ('eps', ctypes.c_float),
-                ('skip_gated_terms', ctypes.c_int32)]
+                ('skip_gated_terms', ctypes.c_int32), ('custom_weights', ctypes.c_int32),
+                ('w_rec', ctypes.c_float), ('w_foot', ctypes.c_float), ('reg_vpose', ctypes.c_float), ('reg_hand', ctypes.c_float),
+                ('reg_eye', ctypes.c_float), ('reg_shape', ctypes.c_float)]
 
 # name -> (restype, argtypes); every symbol include/saga_hip.h declares
 PROTOTYPES = {

@@ -238,7 +238,9 @@ __global__ __launch_bounds__(PK_THREADS) void params_fwd_kernel(const float* __r
     }
 }
 
-struct LossCfg { int stage, only_rec, prior; };
+struct LossCfg { int stage, only_rec, prior, custom; float w_rec, w_foot, reg_vpose, reg_hand, reg_eye, reg_shape; };
+// gradient coefficients of the regularisers, d/dx of w * mean(x^2) = (2 w / n) x  (0: the term is off in this stage)
+struct RegCfg { float c_vpose, c_hand, c_eye; };
 
 // weighted sum of fittingop.py:215-223 (same order of additions) + the gradient of it w.r.t. the eight fused terms
 // Also the workspace's layout check: when the last saga_fit_step on this workspace carved it differently (another B, O,
@@ -255,6 +257,30 @@ __global__ void loss_sum_kernel(const float* __restrict__ terms, const float* __
     for (int k = 0; k < 32; ++k) sv = fmaf(v[SAGA_VAR_VPOSE + k], v[SAGA_VAR_VPOSE + k], sv);
     for (int k = 0; k < 48; ++k) sh = fmaf(v[SAGA_VAR_HAND + k], v[SAGA_VAR_HAND + k], sh);
     for (int k = 0; k < 6; ++k) se = fmaf(v[SAGA_VAR_EYE + k], v[SAGA_VAR_EYE + k], se);
+    if (cfg.custom) {        // marker-fit objective with the caller's weights (GraspMotion-Opt stage 1, :309-325, in its order)
+        float sb = 0.f;
+        for (int k = 0; k < 10; ++k) sb = fmaf(v[SAGA_VAR_BETAS + k], v[SAGA_VAR_BETAS + k], sb);
+        const float rv = cfg.reg_vpose * (sv / 32.f), rs = cfg.reg_shape * (sb / 10.f), rh = cfg.reg_hand * (sh / 48.f),
+                    re = cfg.reg_eye * (se / 6.f);
+        float total = cfg.w_rec * t[0];
+        total += rv;
+        total += rs;
+        total += rh;
+        total += cfg.w_foot * t[2];
+        total += re;
+        loss[b] = total;
+        float* g = g_terms + (size_t)b * NTERM;
+#pragma unroll
+        for (int k = 0; k < NTERM; ++k) g[k] = 0.f;
+        g[0] = cfg.w_rec; g[2] = cfg.w_foot;
+        if (out) {
+            float* o = out + (size_t)b * 16;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) o[k] = 0.f;
+            o[0] = total; o[1] = t[0]; o[2] = t[1]; o[8] = t[2]; o[9] = ((rv + rs) + rh) + re;
+        }
+        return;
+    }
     const float reg_v = 0.0001f * (sv / 32.f), reg_h = 0.0005f * (sh / 48.f), reg_e = 0.0001f * (se / 6.f);
     const float on = cfg.only_rec ? 0.f : 1.f;
     const float s2 = cfg.stage > 1 ? 1.f : 0.f, s1 = cfg.stage > 0 ? 1.f : 0.f;
@@ -288,7 +314,7 @@ __global__ __launch_bounds__(PK_THREADS) void params_bwd_kernel(const float* __r
                                                                 const float* __restrict__ hand_comp,
                                                                 const float* __restrict__ g_pose, const float* __restrict__ g_shape,
                                                                 const float* __restrict__ g_transl, float* __restrict__ grad,
-                                                                float* __restrict__ g_x6, int S, int n_pca, int stage) {
+                                                                float* __restrict__ g_x6, int S, int n_pca, RegCfg reg) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* v = vars + (size_t)b * VS;
     const float* gp = g_pose + (size_t)b * 165;
@@ -305,12 +331,12 @@ __global__ __launch_bounds__(PK_THREADS) void params_bwd_kernel(const float* __r
         const float* gh = gp + 75 + side * 45;
         float acc = 0.f;
         for (int c = 0; c < 45; ++c) acc = fmaf(comp[c], gh[c], acc);
-        if (stage > 1) acc += (2.f * 0.0005f / 48.f) * v[SAGA_VAR_HAND + i];       // d/d hand of 5e-4 * mean(hand^2)
+        if (reg.c_hand != 0.f) acc += reg.c_hand * v[SAGA_VAR_HAND + i];           // d/d hand of 5e-4 * mean(hand^2) (stage 2)
         g[SAGA_VAR_HAND + i] = acc;
     } else if (tid >= 80 && tid < 86) {
         const int k = tid - 80;
         float acc = gp[69 + k];
-        if (stage > 1) acc += (2.f * 0.0001f / 6.f) * v[SAGA_VAR_EYE + k];
+        if (reg.c_eye != 0.f) acc += reg.c_eye * v[SAGA_VAR_EYE + k];
         g[SAGA_VAR_EYE + k] = acc;
     } else if (tid >= 86 && tid < 96) {
         const int k = tid - 86;
@@ -322,7 +348,7 @@ __global__ __launch_bounds__(PK_THREADS) void params_bwd_kernel(const float* __r
     }
 }
 
-struct AdamCfg { int mask, stage; float step_size, beta1, beta2, bc2_sqrt, eps; };
+struct AdamCfg { int mask; float c_vpose, step_size, beta1, beta2, bc2_sqrt, eps; };
 
 __device__ __forceinline__ int var_group(int col) {
     return col < SAGA_VAR_HAND ? SAGA_GROUP_VPOSE
@@ -349,7 +375,7 @@ __global__ void adam_kernel(float* __restrict__ vars, float* __restrict__ m, flo
     float g;
     if (col < SAGA_VAR_HAND) {
         g = g_z[(size_t)b * 128 + col];
-        if (c.stage > 0) g += (2.f * 0.0001f / 32.f) * vars[o];                    // d/dz of 1e-4 * mean(z^2)
+        if (c.c_vpose != 0.f) g += c.c_vpose * vars[o];                            // d/dz of 1e-4 * mean(z^2) (stages 1, 2)
     } else {
         g = grad[o];
     }
@@ -430,6 +456,8 @@ static int fit_step_impl(const saga_model_t* m, const saga_model_t* mb, const sa
     SAGA_CHECK_ARG(m->S >= 10 || m->S == 0, "saga_fit_step: model has %d shape coefficients (< 10 betas)", m->S);
     SAGA_CHECK_ARG(cfg->stage >= 0 && cfg->stage <= 2 && cfg->adam_step >= 1, "saga_fit_step: stage %d / adam step %d",
                    cfg->stage, cfg->adam_step);
+    SAGA_CHECK_ARG(!cfg->custom_weights || (cfg->stage == 0 && cfg->skip_gated_terms),
+                   "saga_fit_step: custom_weights is a marker-fit objective: stage 0 with skip_gated_terms");
     SAGA_CHECK_ARG(prob->n_obj > 0 && prob->obj && prob->obj_normals && prob->markers_target && prob->c_markers && prob->c_object,
                    "saga_fit_step: incomplete problem");
     if (mb) {
@@ -494,7 +522,8 @@ static int fit_step_impl(const saga_model_t* m, const saga_model_t* mb, const sa
         return rc;
     {
         Prof p(SAGA_PROF_LOSS_SUM, stream);
-        LossCfg lc{cfg->stage, cfg->only_rec, cfg->prior_contact};
+        LossCfg lc{cfg->stage, cfg->only_rec, cfg->prior_contact, cfg->custom_weights, cfg->w_rec, cfg->w_foot, cfg->reg_vpose,
+                   cfg->reg_hand,  cfg->reg_eye, cfg->reg_shape};
         loss_sum_kernel<<<(B + 127) / 128, 128, 0, st>>>(w.terms, vars, lc, w.g_terms, loss, loss_terms, B, w.hdr, layout, w.zero_tag);
         SAGA_LAUNCH_CHECK();
     }
@@ -530,10 +559,14 @@ static int fit_step_impl(const saga_model_t* m, const saga_model_t* mb, const sa
                                  w.g_transl, w.gvp, w.slab, w.dA, nullptr, B, stream)))
             return rc;
     }
+    // regulariser gradients: fittingop.py:177-181,215-223 (vpose from stage 1 on, hand and eye in stage 2), or the caller's weights
+    RegCfg reg{cfg->stage > 0 ? 2.f * 0.0001f / 32.f : 0.f, cfg->stage > 1 ? 2.f * 0.0005f / 48.f : 0.f,
+               cfg->stage > 1 ? 2.f * 0.0001f / 6.f : 0.f};
+    if (cfg->custom_weights) reg = RegCfg{2.f * cfg->reg_vpose / 32.f, 2.f * cfg->reg_hand / 48.f, 2.f * cfg->reg_eye / 6.f};
     {
         Prof p(SAGA_PROF_PARAMS_BWD, stream);
         params_bwd_kernel<<<B, PK_THREADS, 0, st>>>(vars, w.jac, d->hand_comp, w.g_pose, w.g_shape, w.g_transl, w.grad, w.g_x6, m->S,
-                                                    d->n_pca, cfg->stage);
+                                                    d->n_pca, reg);
         SAGA_LAUNCH_CHECK();
         if (cfg->update_mask & SAGA_GROUP_VPOSE) {
             // decoder backward: g_h2 = (g_x6 . W3) * lrelu'(h2); g_h1 = (g_h2 . W2) * lrelu'(h1); g_z = g_h1 . W1
@@ -551,7 +584,7 @@ static int fit_step_impl(const saga_model_t* m, const saga_model_t* mb, const sa
         Prof p(SAGA_PROF_ADAM, stream);
         const double bc1 = 1.0 - pow((double)cfg->beta1, (double)cfg->adam_step);
         const double bc2 = 1.0 - pow((double)cfg->beta2, (double)cfg->adam_step);
-        AdamCfg ac{cfg->update_mask, cfg->stage, (float)((double)cfg->lr / bc1), cfg->beta1, cfg->beta2, (float)sqrt(bc2), cfg->eps};
+        AdamCfg ac{cfg->update_mask, reg.c_vpose, (float)((double)cfg->lr / bc1), cfg->beta1, cfg->beta2, (float)sqrt(bc2), cfg->eps};
         const int n = B * SAGA_VAR_COUNT;
         adam_kernel<<<(n + 255) / 256, 256, 0, st>>>(vars, adam_m, adam_v, w.grad, w.g_z, ac, B, w.hdr, layout);
         SAGA_LAUNCH_CHECK();

@@ -43,6 +43,24 @@ def load_grasp_indices(path=None):
     return {k: d[k] for k in ('markers_143', 'markers_f0_p5', 'rhand', 'lhand', 'foot', 'rhand_weight', 'foot_sizes')}
 
 
+def create_decoder(vposer, bm, device):
+    """``saga_decoder_t*`` (VPoser decoder weights + the hand PCA basis / pose mean of ``bm``) on ``device``; the caller frees it
+    with ``saga_decoder_destroy``."""
+    for attr in ('bodyprior_dec_fc1', 'bodyprior_dec_fc2', 'bodyprior_dec_out'):
+        if not hasattr(vposer, attr):
+            raise RuntimeError('native fitting needs a VPoser decoder with bodyprior_dec_fc1/fc2/out layers')
+    h = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)
+    arrs = [h(vposer.bodyprior_dec_fc1.weight), h(vposer.bodyprior_dec_fc1.bias), h(vposer.bodyprior_dec_fc2.weight),
+            h(vposer.bodyprior_dec_fc2.bias), h(vposer.bodyprior_dec_out.weight), h(vposer.bodyprior_dec_out.bias),
+            h(bm.left_hand_components), h(bm.right_hand_components), h(bm.pose_mean)]
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    desc = _lib.DecoderDesc(arrs[0].shape[1], arrs[0].shape[0], arrs[4].shape[0] // 6, arrs[6].shape[0], *[p(a) for a in arrs])
+    out = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        _lib.check(_lib.load().saga_decoder_create(ctypes.byref(out), ctypes.byref(desc)), 'saga_decoder_create')
+    return out
+
+
 def loss_vertex_subset(faces, idx):
     """Ascending ids of the vertices one fitting iteration reads: the 143 markers, the right hand, the feet, and every corner
     of a face that touches a right-hand vertex (the hand's vertex normals sum over its incident faces)."""
@@ -314,19 +332,7 @@ class FittingOP:
         """Decoder constants (VPoser weights + hand PCA of the current body model) and the workspace, created once."""
         key = id(self.bm)
         if self._decoder is None or self._decoder[0] != key:
-            vp, bm = self.vposer, self.bm
-            for attr in ('bodyprior_dec_fc1', 'bodyprior_dec_fc2', 'bodyprior_dec_out'):
-                if not hasattr(vp, attr):
-                    raise RuntimeError('native fitting needs a VPoser decoder with bodyprior_dec_fc1/fc2/out layers')
-            h = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)
-            arrs = [h(vp.bodyprior_dec_fc1.weight), h(vp.bodyprior_dec_fc1.bias), h(vp.bodyprior_dec_fc2.weight),
-                    h(vp.bodyprior_dec_fc2.bias), h(vp.bodyprior_dec_out.weight), h(vp.bodyprior_dec_out.bias),
-                    h(bm.left_hand_components), h(bm.right_hand_components), h(bm.pose_mean)]
-            p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-            desc = _lib.DecoderDesc(arrs[0].shape[1], arrs[0].shape[0], arrs[4].shape[0] // 6, arrs[6].shape[0], *[p(a) for a in arrs])
-            out = ctypes.c_void_p()
-            with torch.cuda.device(self.device):
-                _lib.check(_lib.load().saga_decoder_create(ctypes.byref(out), ctypes.byref(desc)), 'saga_decoder_create')
+            out = create_decoder(self.vposer, self.bm, self.device)
             if self._decoder is not None:
                 _lib.load().saga_decoder_destroy(self._decoder[1])
             self._decoder = (key, out)

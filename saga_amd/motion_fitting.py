@@ -14,10 +14,13 @@ Not part of this path: the learned smoothness prior (``body_smooth_loss`` ``:70-
 with a pretrained snapshot).  Pass ``body_smooth_loss=callable(body_verts [S,T,V,3], body_params [S,T,96]) -> [S]`` in
 the config to add it; without one the term is left out, whatever ``stage2_weight_loss_smooth`` says.
 """
+import ctypes
+
 import numpy as np
 import torch
 import torch.optim as optim
 
+from . import _lib
 from . import smplx as _smplx
 from . import motion_losses as ml
 from .fitting import load_grasp_indices
@@ -80,12 +83,13 @@ class FittingOP:
     and the hand normals read -- the same numbers, see ``_make_picker``), ``fused_terms`` (default True: the seven geometric
     terms of stage 2 as one HIP operator, ``saga_motion_terms_fwd/bwd``; False: their autograd composition in
     ``motion_losses``, the form the tests check it against), ``graph_stage1`` (default True: stage 1 replays one captured
-    iteration, see ``fitting_stage1``)."""
+    iteration, see ``fitting_stage1``), ``native_stage1`` (default True: every stage-1 iteration is one ``saga_fit_step`` call,
+    see ``_fitting_stage1_native``; False: the autograd composition, replayed as a graph or eager)."""
 
     def __init__(self, fittingconfig):
         cfg = dict(T=61, gender='male', device='cuda', n_seq=1, start_t=30, init_lr_stage1=0.1, init_lr_stage2=0.01,
                    num_iter=[100, 300], body_model_path='./body_utils/body_models', vposer=None, smplx_kwargs={},
-                   indices=None, body_smooth_loss=None, sparse_backward=True, reduced_forward=True, fused_terms=True, graph_stage1=True,
+                   indices=None, body_smooth_loss=None, sparse_backward=True, reduced_forward=True, fused_terms=True, graph_stage1=True, native_stage1=True,
                    stage1_weight_loss_rec_markers=1.0, stage1_weight_loss_vposer=0.02, stage1_weight_loss_shape=0.01,
                    stage1_weight_loss_hand=0.01,
                    stage2_weight_loss_rec_markers=0.1, stage2_weight_loss_end_markers_fit=10, stage2_weight_loss_vposer=0.02,
@@ -192,6 +196,8 @@ class FittingOP:
         learning rate are device tensors the graph reads."""
         S, T = self.n_seq, self.T
         rec = torch.as_tensor(body_markers_rec).to(self.device).float().reshape(S, T, -1, 3)
+        if self.native_stage1:
+            return self._fitting_stage1_native(rec)
         params = [self.transl_opt_t, self.rot_6d_opt_t, self.other_params_opt_t]
         graph = bool(self.graph_stage1) and self.num_iter[0] > 0 and T > 0
         if graph:
@@ -240,6 +246,86 @@ class FittingOP:
             out['rot'].append(self.rot_6d_opt_t.detach().clone())
             out['shape'].append(self.shape_t.detach().clone())
             out['other'].append(self.other_params_opt_t.detach().clone())
+        st = lambda k: torch.stack(out[k], dim=1)
+        return st('transl'), st('rot'), st('shape'), st('other'), rec.clone()
+
+    def _stage1_native_handles(self):
+        """(model over the markers, loss tables, decoder, workspace) for ``saga_fit_step`` with the stage-1 objective."""
+        h = self.__dict__.get('_s1_native')
+        if h is None:
+            from .fitting import create_decoder
+            from .grasp_loss import GraspTables
+            bm, pos = self._stage1_model()
+            pos = pos.cpu().numpy()
+            # the marker-fit objective reads the markers only; the hand / foot tables need one valid entry each
+            tables = GraspTables(pos, pos[:1], pos[:1], np.ones(1, dtype=np.float32), self.device)
+            vp = self.vposer_model
+            if not hasattr(vp, 'bodyprior_dec_fc1'):
+                raise RuntimeError('native_stage1 needs a VPoser decoder with bodyprior_dec_fc1/fc2/out layers (native_stage1=False '
+                                   'composes the iteration from the operators instead)')
+            dec = create_decoder(vp, bm, self.device)
+            n = _lib.load().saga_fit_workspace_floats(bm.handle(self.device), ctypes.byref(tables.struct), self.n_seq, 1)
+            h = self._s1_native = dict(bm=bm, tables=tables, decoder=dec, ws=torch.zeros(n, device=self.device))
+        return h
+
+    def __del__(self):
+        h = self.__dict__.get('_s1_native')
+        if h is not None:
+            try:
+                _lib.load().saga_decoder_destroy(h['decoder'])
+            except Exception:
+                pass
+
+    def _fitting_stage1_native(self, rec):
+        """Stage 1 with every iteration as ONE library call: ``saga_fit_step`` with ``custom_weights`` -- variable maps (VPoser
+        MLP, 6D->aa, hand PCA), SMPL-X forward / backward over the 79 markers, marker L1 + regularisers (``:309-325``) and the
+        Adam update of transl / rot6d / latent / hands (torch.optim.Adam arithmetic; the moments carry over from frame to frame as
+        in ``:283-340``) as one sequence of ~20 kernels, no PyTorch kernel in the loop."""
+        S, T, dev = self.n_seq, self.T, self.device
+        h = self._stage1_native_handles()
+        sl = _lib.VAR_SLICES
+        packed = torch.zeros(S, _lib.VAR_STRIDE, device=dev)
+        with torch.no_grad():
+            packed[:, sl['vpose_rec'][0]:sl['vpose_rec'][1]] = self.other_params_opt_t[:, :32]
+            packed[:, sl['hand_pose'][0]:sl['hand_pose'][1]] = self.other_params_opt_t[:, 32:]
+            packed[:, sl['betas'][0]:sl['betas'][1]] = self.shape_t
+            packed[:, sl['transl_rec'][0]:sl['transl_rec'][1]] = self.transl_opt_t
+            packed[:, sl['glo_rot_rec'][0]:sl['glo_rot_rec'][1]] = self.rot_6d_opt_t
+        m, v = torch.zeros_like(packed), torch.zeros_like(packed)
+        dummy3, dummy1 = torch.zeros(S, 1, 3, device=dev), torch.zeros(S, max(h['tables'].n_markers, 1), device=dev)
+        loss, mk_out = torch.empty(S, device=dev), torch.empty(S, h['tables'].n_markers, 3, device=dev)
+        G = _lib.VAR_GROUPS
+        mask = G['vpose_rec'] | G['hand_pose'] | G['transl_rec'] | G['glo_rot_rec']
+        P = _lib.ptr
+        out = {k: [] for k in ('transl', 'rot', 'shape', 'other')}
+        step_count, lr = 0, float(self.init_lr_stage1)
+        for t in range(T):
+            target = rec[:, t].contiguous()
+            prob = _lib.FitProblem(P(dummy3), P(dummy3), P(target), P(dummy1), P(dummy1), 1)
+            if t > 0:
+                lr = 0.005
+            for step in range(self.num_iter[0]):
+                if step > 60:
+                    lr = 0.01
+                if step > 80:
+                    lr = 0.003
+                step_count += 1
+                cfg = _lib.FitStepCfg(0, 0, 0, mask, step_count, lr, 0.9, 0.999, 1e-8, 1, 1,
+                                      float(self.stage1_weight_loss_rec_markers), 0.0, float(self.stage1_weight_loss_vposer),
+                                      float(self.stage1_weight_loss_hand), 0.0, float(self.stage1_weight_loss_shape))
+                _lib.call('saga_fit_step', dev, h['bm'].handle(dev), h['decoder'], ctypes.byref(h['tables'].struct), ctypes.byref(prob),
+                          ctypes.byref(cfg), P(packed), P(m), P(v), P(h['ws']), P(loss), None, P(mk_out), S)
+            out['transl'].append(packed[:, sl['transl_rec'][0]:sl['transl_rec'][1]].clone())
+            out['rot'].append(packed[:, sl['glo_rot_rec'][0]:sl['glo_rot_rec'][1]].clone())
+            out['shape'].append(self.shape_t.detach().clone())
+            out['other'].append(torch.cat([packed[:, sl['vpose_rec'][0]:sl['vpose_rec'][1]],
+                                           packed[:, sl['hand_pose'][0]:sl['hand_pose'][1]]], dim=1))
+        with torch.no_grad():            # the module's variables end where the last frame's fit ended, as in the reference
+            if T > 0:
+                self.transl_opt_t.copy_(out['transl'][-1])
+                self.rot_6d_opt_t.copy_(out['rot'][-1])
+                self.other_params_opt_t.copy_(out['other'][-1])
+        self.last_stage1_loss = loss
         st = lambda k: torch.stack(out[k], dim=1)
         return st('transl'), st('rot'), st('shape'), st('other'), rec.clone()
 

@@ -191,15 +191,18 @@ def test_motion_stage1_matches_oracle(body_model_dir):
 
 
 def test_motion_stage1_graph_replay_and_marker_subset(body_model_dir):
-    """Stage 1 as a replayed HIP graph of one iteration (the default) against the eager loop: the same kernels in the same
-    order; only Adam's capturable form differs (device-side step counter and bias correction).  The body model over the 79
+    """Stage 1 three ways against the eager autograd loop: every iteration as one ``saga_fit_step`` call with the stage-1
+    weights (the default: the library's own decoder GEMMs and Adam kernel), and the autograd iteration replayed as a HIP
+    graph (the same kernels in the same order; only Adam's capturable form differs: device-side step counter and bias correction).  The body model over the 79
     markers gives the full mesh's rows bit for bit; its backward sums fewer (all non-zero) terms.  Both differences are
     rounding (amplified by Adam, whose first steps are +-lr whatever the gradient size): after 5 iterations per frame the three forms agree to 5e-4; over 84 iterations per frame (through the
     learning-rate switches at steps 61 and 81, moments carried from frame to frame) graph and eager loop reach the same marker error."""
     from saga_amd.motion_fitting import convert_to_3D_rot, gen_body_mesh_v1
     S, Tn = 2, 3
     idx, _, vposer, prob = _fit_problem(body_model_dir, S, Tn, 1)
-    modes = [('graph', {}), ('eager', dict(graph_stage1=False)), ('eager full mesh', dict(graph_stage1=False, reduced_forward=False))]
+    off = dict(native_stage1=False)
+    modes = [('native', {}), ('graph', off), ('eager', dict(off, graph_stage1=False)),
+             ('eager full mesh', dict(off, graph_stage1=False, reduced_forward=False))]
 
     def marker_error(op):          # mean |markers - target| of the last frame, per sequence, at the variables the fit left
         with torch.no_grad():
@@ -207,13 +210,13 @@ def test_motion_stage1_graph_replay_and_marker_subset(body_model_dir):
             mk = gen_body_mesh_v1(p, op.smplx_model, op.vposer_model)[0].index_select(1, op.markers_ids)
             return (mk - prob['markers_rec'][:, -1].float().cuda()).abs().mean(dim=(1, 2)).cpu().numpy()
 
-    for n1, which in [(5, modes), (84, modes[:2])]:
+    for n1, which in [(5, modes), (84, modes[:3])]:
         res, err = {}, {}
         for mode, kw in which:
             op = _hip_op(body_model_dir, idx, vposer, prob, S, Tn, 1, [n1, 0])
             for k, v in kw.items():
                 setattr(op, k, v)
-            if n1 == 84 and mode == 'graph':
+            if n1 == 84 and mode == 'native':
                 err['start'] = marker_error(op)
             res[mode] = [t.clone() for t in op.fitting_stage1(prob['markers_rec'])]
             err[mode] = marker_error(op)
@@ -223,9 +226,10 @@ def test_motion_stage1_graph_replay_and_marker_subset(body_model_dir):
                 for name, a, b in zip(('transl', 'rot6d', 'shape', 'other'), res[mode], res['eager']):
                     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=5e-4, rtol=0, err_msg='%s %s' % (mode, name))
         else:       # 252 Adam steps amplify the rounding differences in the variables; the fits are equally good
-            assert (err['graph'] < 0.5 * err['start']).all(), err
-            np.testing.assert_allclose(err['graph'], err['eager'], rtol=0.05)
-        assert (res['graph'][0][:, 1] - res['graph'][0][:, 0]).abs().max() > 0     # frames continue from the previous result
+            for mode in ('native', 'graph'):
+                assert (err[mode] < 0.5 * err['start']).all(), err
+                np.testing.assert_allclose(err[mode], err['eager'], rtol=0.05, err_msg=mode)
+        assert (res['native'][0][:, 1] - res['native'][0][:, 0]).abs().max() > 0     # frames continue from the previous result
 
 
 def test_motion_stage2_matches_oracle(body_model_dir):
