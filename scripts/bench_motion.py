@@ -19,6 +19,7 @@ ap.add_argument('--warmup', type=int, default=2)
 ap.add_argument('--dense-backward', action='store_true', help='dense [S*T,V,3] vertex gradient (the form the reference has)')
 ap.add_argument('--full-forward', action='store_true', help='evaluate the whole mesh in the forward (reduced_forward=False)')
 ap.add_argument('--mesh-faces', action='store_true', help='mesh-like synthetic model (id-local faces and weights)')
+ap.add_argument('--whole-fit', action='store_true', help='time a whole two-stage fit (T x 100 stage-1 iterations, 300 stage-2 iterations)')
 a = ap.parse_args()
 S, T, start_t = a.sequences, a.frames, 30
 tmp = tempfile.TemporaryDirectory()
@@ -47,6 +48,25 @@ vo = (vo - vo.mean(1, keepdim=True) + centre[:, None])[:, None].expand(S, T - st
 no = torch.from_numpy(no).float().cuda()[:, None].expand(S, T - start_t, -1, 3).contiguous()
 lbl = (torch.rand(S, T, 4, generator=g) > 0.4).float()
 c_obj, c_mk = torch.rand(S, 2048, generator=g), torch.rand(S, 143, generator=g)
+if a.whole_fit:
+    op.num_iter = [100, 300]
+    op.init_param_t()
+    out = {}
+    for name in ('warm-up', 'timed'):
+        op.init_param_t()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        tr, ro, sh, ot, mk = op.fitting_stage1(markers_rec)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        op.init_param_T(tr.detach(), ro.detach(), ot.detach(), sh.detach())
+        op.fitting_stage2(mk, markers_end, idx['rhand'], lbl, c_obj, c_mk, no, vo)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        out = {'stage1_s': round(t1 - t0, 3), 'stage2_s': round(t2 - t1, 3), 'total_s': round(t2 - t0, 3)}
+        if name == 'warm-up':
+            op.num_iter = [100, 300]
+    print(json.dumps({'config': 'GraspMotion-Opt whole fit, %d sequences x %d frames: %d x 100 stage-1 + 300 stage-2 iterations' % (S, T, T),
+                      'model': 'mesh-like faces, local weights' if a.mesh_faces else 'SURVEY synthetic (random faces and joints)', **out,
+                      'sequences_per_s': round(S / out['total_s'], 1), 'data': 'synthetic'}))
+    sys.exit(0)
 run = lambda n: (setattr(op, 'num_iter', [0, n]), op.fitting_stage2(markers_rec, markers_end, idx['rhand'], lbl, c_obj, c_mk, no, vo))
 run(a.warmup)
 torch.cuda.synchronize()

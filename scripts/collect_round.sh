@@ -13,4 +13,5 @@ run bench_autograd python3 bench.py --autograd --no-cpu-baseline
 run config4_motion python3 scripts/bench_motion.py
 run config4_motion_mesh_like python3 scripts/bench_motion.py --mesh-faces
 run config4_motion_full_forward python3 scripts/bench_motion.py --full-forward
+run config4_motion_whole_fit python3 scripts/bench_motion.py --whole-fit
 run whole_fit python3 scripts/bench_fit.py
