@@ -354,3 +354,11 @@ def test_vertex_normals_lds_staged_kernel_equals_gather_kernel(body_model_dir):
     assert torch.equal(got_sub, got_full[:, sel.long()]) and got_full[7].abs().max() == 0
     small = vertex_normals_subset(bm, verts[:4].contiguous(), sel)           # below the threshold: the gather kernel
     assert torch.equal(small, got_sub[:4])
+    # saga_vertex_normals_subset_window: the frames t0.. of [S,T,V,3] without copying the slice -- both kernels
+    for S, T, t0 in [(103, 5, 2), (2, 5, 4), (3, 4, 0)]:
+        seq = verts[:S * T].reshape(S, T, 10475, 3)
+        win = vertex_normals_subset(bm, seq, sel, first_frame=t0)
+        ref = vertex_normals_subset(bm, seq[:, t0:].reshape(S * (T - t0), 10475, 3).contiguous(), sel)
+        assert win.shape == ref.shape and torch.equal(win, ref), (S, T, t0)
+    with pytest.raises(ValueError):
+        vertex_normals_subset(bm, verts[:6].reshape(2, 3, 10475, 3), sel, first_frame=3)

@@ -493,3 +493,49 @@ def test_unlogged_gated_terms_give_the_same_fit(body_model_dir):
     for k in p_a[-1]:
         np.testing.assert_allclose(p_b[-1][k].cpu().numpy(), p_a[-1][k].cpu().numpy(), atol=2e-3, err_msg=k)
     np.testing.assert_allclose(mf_b[0], mf_a[0], atol=2e-4)
+
+
+def test_custom_weights_objective_through_the_c_abi(body_model_dir):
+    """saga_fit_step_cfg_t.custom_weights (the marker-fit objective GraspMotion-Opt stage 1 runs on): the loss is the caller's
+    weighted sum of the reconstruction / foot terms the same call reports and the four regularisers; variables only the
+    regulariser reaches (the eye pose: no marker sits on an eye) take the Adam first step -lr * sign(x); the switch is refused
+    outside stage 0 with skip_gated_terms."""
+    import ctypes
+    from saga_amd import _lib
+    B, lr = 3, 0.01
+    op, vp, idx, var_np, d = _setup(body_model_dir, B)
+    op.bm = op.bm_male
+    op.set_variables(var_np)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    prob = op.make_problem(cu(d['markers']), cu(d['verts_o']), cu(d['normals_o']), cu(d['oc']), cu(d['mc']))
+    before = op.vars.clone()
+    terms = torch.zeros(B, 16, device='cuda')
+    m, v = torch.zeros_like(op.vars), torch.zeros_like(op.vars)
+    G = _lib.VAR_GROUPS
+    mask = G['vpose_rec'] | G['hand_pose'] | G['eye_pose'] | G['transl_rec'] | G['glo_rot_rec']
+    w = dict(w_rec=2.0, w_foot=0.5, reg_vpose=0.02, reg_hand=0.01, reg_eye=0.03, reg_shape=0.01)
+    P = _lib.ptr
+    args = lambda cfg: ('saga_fit_step', op.device, op.bm.handle(op.device), op._native_handles(), ctypes.byref(op._tstruct()),
+                        ctypes.byref(prob['struct']), ctypes.byref(cfg), P(op.vars), P(m), P(v), P(op._workspace(2048)), P(prob['loss']),
+                        P(terms), P(prob['markers_rec']), B)
+    _lib.call(*args(_lib.FitStepCfg(0, 0, 0, mask, 1, lr, 0.9, 0.999, 1e-8, 1, 1, *w.values())))
+    sl = _lib.VAR_SLICES
+    msq = lambda k: (before[:, sl[k][0]:sl[k][1]] ** 2).mean(dim=1)
+    expect = (w['w_rec'] * terms[:, 1] + w['w_foot'] * terms[:, 8] + w['reg_vpose'] * msq('vpose_rec') + w['reg_shape'] * msq('betas')
+              + w['reg_hand'] * msq('hand_pose') + w['reg_eye'] * msq('eye_pose'))
+    assert (terms[:, 1] > 0).all() and (terms[:, 8] > 0).all()
+    np.testing.assert_allclose(prob['loss'].cpu().numpy(), expect.cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(terms[:, 0].cpu().numpy(), prob['loss'].cpu().numpy(), rtol=0, atol=0)
+    assert torch.equal(op.vars[:, slice(*sl['betas'])], before[:, slice(*sl['betas'])])           # not in the update mask
+    assert (op.vars[:, slice(*sl['transl_rec'])] != before[:, slice(*sl['transl_rec'])]).all()
+    # a regulariser weight that swamps the data term: Adam's first step is -lr * sign(x) on those variables
+    op.vars.copy_(before); m.zero_(); v.zero_()
+    _lib.call(*args(_lib.FitStepCfg(0, 0, 0, mask, 1, lr, 0.9, 0.999, 1e-8, 1, 1, *dict(w, reg_eye=1e6, reg_hand=1e6).values())))
+    for k in ('eye_pose', 'hand_pose'):
+        c = slice(*sl[k])
+        np.testing.assert_allclose((op.vars[:, c] - before[:, c]).cpu().numpy(), (-lr * torch.sign(before[:, c])).cpu().numpy(),
+                                   rtol=1e-4, atol=1e-9, err_msg=k)
+    for bad in (_lib.FitStepCfg(1, 0, 0, mask, 2, lr, 0.9, 0.999, 1e-8, 1, 1, *w.values()),
+                _lib.FitStepCfg(0, 0, 0, mask, 2, lr, 0.9, 0.999, 1e-8, 0, 1, *w.values())):
+        with pytest.raises(RuntimeError, match='custom_weights'):
+            _lib.call(*args(bad))
