@@ -84,12 +84,13 @@ class FittingOP:
     terms of stage 2 as one HIP operator, ``saga_motion_terms_fwd/bwd``; False: their autograd composition in
     ``motion_losses``, the form the tests check it against), ``graph_stage1`` (default True: stage 1 replays one captured
     iteration, see ``fitting_stage1``), ``native_stage1`` (default True: every stage-1 iteration is one ``saga_fit_step`` call,
-    see ``_fitting_stage1_native``; False: the autograd composition, replayed as a graph or eager)."""
+    see ``_fitting_stage1_native``; False: the autograd composition, replayed as a graph or eager), ``graph_stage2`` ('auto':
+    stage 2 replays one captured iteration when an iteration is launch-bound, i.e. up to 2,048 bodies; True / False force it)."""
 
     def __init__(self, fittingconfig):
         cfg = dict(T=61, gender='male', device='cuda', n_seq=1, start_t=30, init_lr_stage1=0.1, init_lr_stage2=0.01,
                    num_iter=[100, 300], body_model_path='./body_utils/body_models', vposer=None, smplx_kwargs={},
-                   indices=None, body_smooth_loss=None, sparse_backward=True, reduced_forward=True, fused_terms=True, graph_stage1=True, native_stage1=True,
+                   indices=None, body_smooth_loss=None, sparse_backward=True, reduced_forward=True, fused_terms=True, graph_stage1=True, native_stage1=True, graph_stage2='auto',
                    stage1_weight_loss_rec_markers=1.0, stage1_weight_loss_vposer=0.02, stage1_weight_loss_shape=0.01,
                    stage1_weight_loss_hand=0.01,
                    stage2_weight_loss_rec_markers=0.1, stage2_weight_loss_end_markers_fit=10, stage2_weight_loss_vposer=0.02,
@@ -460,17 +461,57 @@ class FittingOP:
         normal_object, verts_object = f(normal_object, S, T - self.start_t, O, 3), f(verts_object, S, T - self.start_t, O, 3)
         rhand_verts = torch.as_tensor(np.asarray(rhand_verts), dtype=torch.long, device=dev)
         self._make_picker(rhand_verts)
-        self.optimizer_s2 = optim.Adam([self.transl_opt_T, self.rot_6d_opt_T, self.other_params_opt_T], lr=self.init_lr_stage2)
-        for step in range(self.num_iter[1]):
-            if step > 150:
-                self._set_lr(self.optimizer_s2, 0.005)
-            self.optimizer_s2.zero_grad()
-            total, terms = self.stage2_losses(markers_rec_T, markers_end_new, rhand_verts, contact_lbl_rec, contact_object,
-                                              contact_markers, normal_object, verts_object)
+        params = [self.transl_opt_T, self.rot_6d_opt_T, self.other_params_opt_T]
+        args = (markers_rec_T, markers_end_new, rhand_verts, contact_lbl_rec, contact_object, contact_markers, normal_object, verts_object)
+
+        def iteration():
+            self.optimizer_s2.zero_grad(set_to_none=True)
+            total, terms = self.stage2_losses(*args)
             total.sum().backward()
             self.optimizer_s2.step()
-            if record is not None:
-                record(step, total.detach(), {k: v.detach() for k, v in terms.items()})
+            return total.detach(), {k: v.detach() for k, v in terms.items()}
+
+        # Few bodies per iteration (one sequence = 61: what the reference runs) leave the ~250 launches of an iteration
+        # launch-bound (1.9 ms at S = 1 against 0.2 ms of kernel time): one iteration is captured in a HIP graph and replayed,
+        # the learning rate a device tensor.  Large batches are GPU-bound and run eagerly.  (A body_smooth_loss hook is user code:
+        # eager.)
+        graph = self.graph_stage2
+        if graph == 'auto':
+            graph = S * T <= 2048
+        graph = bool(graph) and self.num_iter[1] > 0 and self.body_smooth_loss is None
+        if not graph:
+            self.optimizer_s2 = optim.Adam(params, lr=self.init_lr_stage2)
+            for step in range(self.num_iter[1]):
+                if step > 150:
+                    self._set_lr(self.optimizer_s2, 0.005)
+                total, terms = iteration()
+                if record is not None:
+                    record(step, total, terms)
+            return self.transl_opt_T, self.rot_6d_opt_T, self.shape_T, self.other_params_opt_T
+        lr = torch.tensor(float(self.init_lr_stage2), device=dev)
+        self.optimizer_s2 = optim.Adam(params, lr=lr, capturable=True)
+        keep = [q.detach().clone() for q in params]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):          # warm-up off the capture, then variables and Adam state go back
+            for _ in range(2):
+                iteration()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        with torch.no_grad():
+            for q, k in zip(params, keep):
+                q.copy_(k)
+            for st in self.optimizer_s2.state.values():
+                st['step'].zero_(); st['exp_avg'].zero_(); st['exp_avg_sq'].zero_()
+        self.optimizer_s2.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            total, terms = iteration()
+        for step in range(self.num_iter[1]):
+            if step == 151:
+                lr.fill_(0.005)
+            g.replay()
+            if record is not None:             # (the graph's output tensors: valid until the next replay)
+                record(step, total.clone(), {k: v.clone() for k, v in terms.items()})
         return self.transl_opt_T, self.rot_6d_opt_T, self.shape_T, self.other_params_opt_T
 
     def fitting(self, body_markers_rec, markers_end_new, rhand_verts, contact_lbl_rec, contact_object, contact_markers,

@@ -360,6 +360,39 @@ def test_motion_fused_terms_match_composition(body_model_dir):
         assert torch.equal(a, b)
 
 
+def test_motion_stage2_graph_replay_matches_eager(body_model_dir):
+    """Stage 2 as a replayed HIP graph of one iteration (the default for small batches) against the eager loop: the same
+    kernels; Adam in its capturable form.  First iteration equal to 1e-6, later totals within 5e-3, variables within 2e-3 after 6
+    iterations; the recorded totals and terms are those of the iteration they are reported for."""
+    S, Tn, start_t, n2 = 2, 9, 4, 6
+    idx, _, vposer, prob = _fit_problem(body_model_dir, S, Tn, start_t, seed=60)
+    g = torch.Generator().manual_seed(5)
+    transl = torch.tensor([0.0, 0.4, 1.0]) + 0.02 * torch.rand(S, Tn, 3, generator=g)
+    rot6 = torch.tensor([-1., 0, 0, 0, 0, 1]).expand(S, Tn, 6) + 0.05 * torch.randn(S, Tn, 6, generator=g)
+    other = 0.1 * torch.randn(S, Tn, 80, generator=g)
+    shape = prob['beta'][:, None].expand(S, Tn, 10).float().contiguous()
+    res = {}
+    for mode, flag in [('graph', True), ('eager', False)]:
+        op = _hip_op(body_model_dir, idx, vposer, prob, S, Tn, start_t, [0, n2])
+        op.graph_stage2 = flag
+        op.init_param_T(transl, rot6, other, shape.numpy())
+        hist = []
+        out = op.fitting_stage2(prob['markers_rec'], prob['markers_end'], idx['rhand'], prob['lbl'], prob['c_obj'], prob['c_mk'],
+                                prob['no'], prob['vo'], record=lambda i, tot, terms: hist.append((tot.cpu(), {k: v.cpu() for k, v in terms.items()})))
+        res[mode] = (hist, [t.detach().clone() for t in out])
+    assert len(res['graph'][0]) == n2
+    for i, ((tg, dg), (te, de)) in enumerate(zip(res['graph'][0], res['eager'][0])):
+        # the first iteration is the same arithmetic; later ones differ by Adam's two forms, amplified by the discontinuous
+        # collision / skating / angle masks (the bar of the oracle test above)
+        np.testing.assert_allclose(tg.numpy(), te.numpy(), rtol=1e-6 if i == 0 else 5e-3, err_msg='iteration %d' % i)
+        if i == 0:
+            for k in de:
+                np.testing.assert_allclose(dg[k].numpy(), de[k].numpy(), rtol=1e-6, atol=1e-9, err_msg=k)
+    assert not torch.equal(res['graph'][0][0][0], res['graph'][0][-1][0])          # the totals move from iteration to iteration
+    for a, b in zip(res['graph'][1], res['eager'][1]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-3, rtol=0)
+
+
 def test_motion_fitting_sequences_are_independent(body_model_dir):
     """The batched driver gives each sequence the result of its own run: S = 2 equals two S = 1 runs up to the rounding
     of the torch / rocBLAS pieces whose reduction order depends on the batch shape (VPoser linears, means)."""
