@@ -38,6 +38,23 @@ def test_argument_errors_have_messages():
     rc = lib.saga_smplx_fwd(None, None, None, None, None, None, None, None, None, None, None, None, 1, None)
     assert rc == -1 and b'null model' in lib.saga_last_error()
     assert lib.saga_chamfer_fwd(None, None, None, None, None, None, 0, 4, 4, None) == 0     # empty batch is a no-op
+    # round-2 entry points: sizes and nulls are refused with a message before anything touches a device
+    import ctypes
+    assert lib.saga_p2p_signed_fwd(None, None, None, None, None, None, None, None, None, None, 1, 4, 0, None) == -1
+    assert b'empty cloud' in lib.saga_last_error()
+    sets = (_lib.PickSet * 1)(_lib.PickSet(n=0, t0=0))
+    assert lib.saga_pick_sets_fwd(None, sets, 1, 2, 3, 10, None) == -1 and b'set 0' in lib.saga_last_error()
+    assert lib.saga_pick_sets_fwd(None, sets, 9, 2, 3, 10, None) == -1 and b'sets' in lib.saga_last_error()
+    sets = (_lib.PickSet * 1)(_lib.PickSet(n=4, t0=3))
+    assert lib.saga_pick_sets_bwd(sets, 1, None, 2, 3, 10, None) == -1 and b't0=3' in lib.saga_last_error()
+    cfg = _lib.MotionTermsCfg(n_seq=2, n_frames=1, n_tail=1, n_markers=79, foot_group_size=(ctypes.c_int32 * 4)(1, 1, 1, 1), n_hand=778,
+                              n_obj=2048, n_contact_markers=143, n_palm=22, n_last_frames=5, vel_thres=0.1)
+    assert lib.saga_motion_terms_fwd(ctypes.byref(cfg), *([None] * 14), None) == -1 and b'bad sizes' in lib.saga_last_error()
+    cfg.n_frames, cfg.n_tail, cfg.n_palm = 61, 31, 200
+    assert lib.saga_motion_terms_fwd(ctypes.byref(cfg), *([None] * 14), None) == -1 and b'set sizes' in lib.saga_last_error()
+    cfg.n_palm = 22
+    assert lib.saga_motion_terms_bwd(ctypes.byref(cfg), *([None] * 21), None) == -1 and b'null argument' in lib.saga_last_error()
+    assert lib.saga_vertex_normals_subset_window(None, None, None, 0, None, 2, 3, 3, None) == -1 and b't0=3' in lib.saga_last_error()
 
 
 def test_constants_match_header():
