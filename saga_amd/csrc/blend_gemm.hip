@@ -22,7 +22,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // three tiles in flight beside the one being multiplied (4 stages = 64 KB, two blocks per CU) run the forward shape at
 // 125 TFLOP/s and the split-K backward at 131 (5 stages: 134); 32-deep/2-stage gives 106/107.
 #define GEMM_BKT 16         // k-depth of an LDS tile
+#ifndef GEMM_NST_FWD
 #define GEMM_NST_FWD 4      // LDS stages, forward
+#endif
 #define GEMM_NST_BWD 5      // LDS stages, backward (split-K)
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -31,7 +33,9 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 template <int N>
 __device__ __forceinline__ void gemm_wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
                                                           const float* __restrict__ Bt, int ldb, float* __restrict__ C,
                                                           int ldc, const float* __restrict__ bias,
                                                           const float* __restrict__ aux, int M, int N, int K,
-                                                          int kchunk, int tiles_m, int xcd_map = 0) {
+                                                          int kchunk, int tiles_m, int xcd_map = 0, int n_tiles_x = 0) {
     constexpr int TBM = 64 * WT, TBN = 64 * WT;      // block tile
     constexpr int TILE_FLOATS = TBM * BKT;           // one operand tile
     constexpr int PPW = TILE_FLOATS * 4 / 1024 / 4;  // 1-KiB LDS-DMA pieces per wave per operand tile: 4 (BKT 32) / 2 (16)
@@ -65,15 +69,20 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     // ONE shared array (a second LDS object beside an LDS-DMA target makes hipcc drain vmcnt before every ds_read)
     __shared__ __attribute__((aligned(1024))) float smem[NST * 2 * TILE_FLOATS];   // [stage][A|B][128][BKT]
 
+    // n_tiles_x > gridDim.x: a PERSISTENT launch -- a block walks the x tiles bx = blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x a
+    // multiple of 8, so a block's tiles stay on its XCD's share of the ownership map below); 0: one tile per block
+    if (n_tiles_x == 0) n_tiles_x = gridDim.x;
+    for (int bx = blockIdx.x; bx < n_tiles_x; bx += gridDim.x) {
+    if (bx != (int)blockIdx.x) __syncthreads();      // every wave has left the previous tile's last LDS stage
     // consecutive blocks walk M first so the (large, batch-shared) Bt tile stays hot in L2 while A is re-read
-    int tile_m = blockIdx.x % tiles_m;
-    int tile_n = blockIdx.x / tiles_m;
+    int tile_m = bx % tiles_m;
+    int tile_n = bx / tiles_m;
     int slab = blockIdx.z;
     if (xcd_map == 2) {
         // split-K launch (gridDim.z a multiple of 8): XCD x owns the slabs z = x (mod 8) entirely, so every A and B tile of the
         // launch is fetched by exactly one L2 (linear workgroup id = z * gridDim.x + x, dealt to the XCDs round-robin)
-        const int per = gridDim.x;
-        const int L = blockIdx.z * per + blockIdx.x;
+        const int per = n_tiles_x;
+        const int L = blockIdx.z * per + bx;
         const int x = L & 7, i = L >> 3;
         slab = x + 8 * (i / per);
         const int t = i % per, tiles_n = per / tiles_m;
@@ -82,8 +91,8 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     } else if (xcd_map) {
         // workgroups go to the 8 XCDs round-robin: XCD x owns a quarter of the M tiles (its A rows stay in its L2) and half of the
         // N tiles, so a Bt tile is fetched by four L2s instead of eight (host checks tiles_m % 4 == 0 and tiles_n % 2 == 0)
-        const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
-        const int mq = tiles_m >> 2, nh = (gridDim.x / tiles_m) >> 1;
+        const int x = bx & 7, i = bx >> 3;
+        const int mq = tiles_m >> 2, nh = (n_tiles_x / tiles_m) >> 1;
         tile_m = (x & 3) * mq + i % mq;
         tile_n = (x >> 2) * nh + i / mq;
     }
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
             }
             __builtin_amdgcn_wave_barrier();
         }
-        return;
+        continue;
     }
     if (TRS) {
         // transposed tiles: row = lane&31, col = (r&3) + 8*(r>>2) + 4*(lane>>5): one 16-B store per register quad
@@ -241,11 +250,14 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
                         v.x = x.x > 0.f ? v.x : 0.2f * v.x; v.y = x.y > 0.f ? v.y : 0.2f * v.y;
                         v.z = x.z > 0.f ? v.z : 0.2f * v.z; v.w = x.w > 0.f ? v.w : 0.2f * v.w;
                     }
+#ifdef GEMM_EXP_NO_STORE        // timing experiment: what the epilogue's stores cost (wrong results)
+                    if (v.x == 123.456f)
+#endif
                     *reinterpret_cast<float4*>(Cz + off) = v;
                 }
             }
         }
-        return;
+        continue;
     }
 #pragma unroll
     for (int nt = 0; nt < WT; ++nt) {
@@ -275,6 +287,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
             }
         }
     }
+    }       // tiles of this block
 }
 
 // v_posed[B,Npad] = v_template + feat . Bt^T
@@ -290,9 +303,28 @@ int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed
     if (want_lepi)
         gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD, 2, true, true><<<grid, 256, 0, st>>>(feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template,
                                                                                             nullptr, B, m->Npad, FEAT_K, FEAT_K, tiles_m, xcd_map);
-    else
+    else {
+        // persistent launch: two blocks per CU (what the 64 KB of LDS stages allow) walk the tiles -- no block turnover between
+        // tiles: 1.068 -> 1.059 ms at B = 4096 (SAGA_GEMM_PERSIST=0: one block per tile; =n: n blocks).  What the per-tile
+        // overheads are worth in all (measured with -DGEMM_EXP_NO_STORE, wrong results): no epilogue stores at all 1.027 ms.
+        static const int persist_env = getenv("SAGA_GEMM_PERSIST") ? atoi(getenv("SAGA_GEMM_PERSIST")) : -1;
+        int persist = persist_env;
+        if (persist < 0) {
+            static int n_cu = 0;
+            if (n_cu == 0) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+                else n_cu = 256;
+            }
+            persist = 2 * n_cu;
+        }
+        persist &= ~7;          // a multiple of 8: a block's tiles stay on one XCD's share of the ownership map
+        const int n_tiles = tiles_m * tiles_n;
+        if (persist > 0 && n_tiles > persist) grid.x = persist;
         gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD><<<grid, 256, 0, st>>>(feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template, nullptr, B, m->Npad,
-                                                    FEAT_K, FEAT_K, tiles_m, xcd_map);
+                                                    FEAT_K, FEAT_K, tiles_m, xcd_map, n_tiles);
+    }
     SAGA_LAUNCH_CHECK();
     return 0;
 }
