@@ -90,7 +90,8 @@ class FittingOP:
     def __init__(self, fittingconfig):
         cfg = dict(T=61, gender='male', device='cuda', n_seq=1, start_t=30, init_lr_stage1=0.1, init_lr_stage2=0.01,
                    num_iter=[100, 300], body_model_path='./body_utils/body_models', vposer=None, smplx_kwargs={},
-                   indices=None, body_smooth_loss=None, sparse_backward=True, reduced_forward=True, fused_terms=True, graph_stage1=True, native_stage1=True, graph_stage2='auto',
+                   indices=None, body_smooth_loss=None, sparse_backward=True, reduced_forward=True, fused_terms=True,
+                   native_stage1=True, graph_stage1=True, graph_stage2='auto',
                    stage1_weight_loss_rec_markers=1.0, stage1_weight_loss_vposer=0.02, stage1_weight_loss_shape=0.01,
                    stage1_weight_loss_hand=0.01,
                    stage2_weight_loss_rec_markers=0.1, stage2_weight_loss_end_markers_fit=10, stage2_weight_loss_vposer=0.02,
@@ -191,8 +192,10 @@ class FittingOP:
         """``:283-340``.  body_markers_rec [S,T,79,3] (or [T,79,3] when S = 1) -> transl [S,T,3], rot6d [S,T,6],
         shape [S,T,10], other [S,T,80], markers [S,T,79,3].
 
-        The T x num_iter[0] iterations are small (S bodies, 79 vertices) and launch-bound -- ~150 launches of a few microseconds
-        each -- so with ``graph_stage1`` (default) ONE iteration is captured in a HIP graph (``torch.cuda.CUDAGraph``; the
+        The T x num_iter[0] iterations are small (S bodies, 79 vertices) and, composed from the operators under autograd,
+        launch-bound -- ~150 launches of a few microseconds each.  Default (``native_stage1``): every iteration is one
+        ``saga_fit_step`` call (``_fitting_stage1_native``).  Otherwise, with ``graph_stage1``, ONE autograd iteration is captured
+        in a HIP graph (``torch.cuda.CUDAGraph``; the
         library's operators enqueue on the capturing stream and allocate nothing) and replayed: the frame's targets and the
         learning rate are device tensors the graph reads."""
         S, T = self.n_seq, self.T
