@@ -295,15 +295,17 @@ int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed
     const int tiles_m = (B + BM - 1) / BM, tiles_n = m->Npad / BN;
     dim3 grid(tiles_m * tiles_n, 1, 1);
     static const int want_xcd = getenv("SAGA_GEMM_XCD") ? atoi(getenv("SAGA_GEMM_XCD")) : 1;     // SAGA_GEMM_XCD=0: plain tile order (A/B)
-    const int xcd_map = want_xcd && tiles_m % 4 == 0 && tiles_n % 2 == 0;
+    int xcd_map = want_xcd && tiles_m % 4 == 0 && tiles_n % 2 == 0;
+    int n_tiles = tiles_m * tiles_n;
     // whole-line non-temporal epilogue (LEPI, SAGA_GEMM_LEPI=1): the 516 MB of output no longer displaces the operands in L2 -- HBM-side
     // traffic of the launch 1.14 -> 0.81 GB, same bits -- but the launch is 0.8 % slower and the skinning forward, which then finds
     // nothing of v_posed in the Infinity Cache, 0.013 ms slower: 4.324 against 4.300 ms per iteration.  Off by default: time wins.
     static const int want_lepi = getenv("SAGA_GEMM_LEPI") ? atoi(getenv("SAGA_GEMM_LEPI")) : 0;
-    if (want_lepi)
+    if (want_lepi) {
+        grid.x = n_tiles;
         gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD, 2, true, true><<<grid, 256, 0, st>>>(feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template,
-                                                                                            nullptr, B, m->Npad, FEAT_K, FEAT_K, tiles_m, xcd_map);
-    else {
+                                                                                            nullptr, B, m->Npad, FEAT_K, FEAT_K, tiles_m, xcd_map, n_tiles);
+    } else {
         // persistent launch: two blocks per CU (what the 64 KB of LDS stages allow) walk the tiles -- no block turnover between
         // tiles: 1.068 -> 1.059 ms at B = 4096 (SAGA_GEMM_PERSIST=0: one block per tile; =n: n blocks).  What the per-tile
         // overheads are worth in all (measured with -DGEMM_EXP_NO_STORE, wrong results): no epilogue stores at all 1.027 ms.
@@ -320,7 +322,7 @@ int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed
             persist = 2 * n_cu;
         }
         persist &= ~7;          // a multiple of 8: a block's tiles stay on one XCD's share of the ownership map
-        const int n_tiles = tiles_m * tiles_n;
+        grid.x = n_tiles;
         if (persist > 0 && n_tiles > persist) grid.x = persist;
         gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD><<<grid, 256, 0, st>>>(feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template, nullptr, B, m->Npad,
                                                     FEAT_K, FEAT_K, tiles_m, xcd_map, n_tiles);
