@@ -359,6 +359,18 @@ typedef struct {
 int  saga_decoder_create(saga_decoder_t** out, const saga_decoder_desc_t* desc);
 void saga_decoder_destroy(saga_decoder_t* d);
 
+/* The parameter maps alone, for callers that keep their own objective under autograd (GraspMotion-Opt stage 2,
+ * MotionFill/models/fittingop.py:356-358 -> utils/utils_body.py:93-106: convert_to_3D_rot + VPoser decode + the hand PCA inside
+ * smplx): packed variable rows [B,SAGA_VAR_STRIDE] -> full_pose [B,165] (pose mean added), shape [B,n_shape] (betas, then
+ * zeros), transl [B,3]; and the reverse map of the gradients -> grad_vars [B,SAGA_VAR_STRIDE] (g_shape / g_transl may be NULL).
+ *   ws: saga_params_workspace_floats(d, B) floats, the SAME buffer for the forward and the backward of one evaluation (it
+ *       carries the decoder activations and the 6D->aa Jacobians); the backward may run once per forward. */
+size_t saga_params_workspace_floats(const saga_decoder_t* d, int B);
+int saga_params_fwd(const saga_decoder_t* d, const float* vars, float* full_pose, float* shape, float* transl, int n_shape,
+                    float* ws, int B, void* stream);
+int saga_params_bwd(const saga_decoder_t* d, const float* vars, const float* g_full_pose, const float* g_shape,
+                    const float* g_transl, float* grad_vars, int n_shape, float* ws, int B, void* stream);
+
 typedef struct {                 /* per-candidate fitting targets, DEVICE pointers (opt_grasppose.py:211-226) */
     const float* obj;            /* [B,O,3] object points   */
     const float* obj_normals;    /* [B,O,3]                 */

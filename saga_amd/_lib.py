@@ -127,6 +127,10 @@ PROTOTYPES = {
                                            ctypes.c_int, c_stream]),
     'saga_pick_sets_fwd': (ctypes.c_int, [c_float_p, ctypes.POINTER(PickSet), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
     'saga_pick_sets_bwd': (ctypes.c_int, [ctypes.POINTER(PickSet), ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    'saga_params_workspace_floats': (ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_int]),
+    'saga_params_fwd': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, c_stream]),
+    'saga_params_bwd': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_float_p,
+                                       ctypes.c_int, c_stream]),
     'saga_motion_terms_fwd': (ctypes.c_int, [ctypes.POINTER(MotionTermsCfg)] + [c_float_p] * 14 + [c_stream]),
     'saga_motion_terms_bwd': (ctypes.c_int, [ctypes.POINTER(MotionTermsCfg)] + [c_float_p] * 21 + [c_stream]),
     'saga_vertex_normals': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_int, c_stream]),

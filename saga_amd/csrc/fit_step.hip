@@ -342,7 +342,7 @@ __global__ __launch_bounds__(PK_THREADS) void params_bwd_kernel(const float* __r
         const int k = tid - 86;
         g[SAGA_VAR_BETAS + k] = k < S ? g_shape[(size_t)b * S + k] : 0.f;
     } else if (tid >= 96 && tid < 99) {
-        g[SAGA_VAR_TRANSL + (tid - 96)] = g_transl[(size_t)b * 3 + (tid - 96)];
+        g[SAGA_VAR_TRANSL + (tid - 96)] = g_transl ? g_transl[(size_t)b * 3 + (tid - 96)] : 0.f;
     } else if (tid >= 126) {
         g_x6[(size_t)b * X6_LD + tid] = 0.f;      // columns 126, 127 of the decoder-output gradient
     }
@@ -429,6 +429,75 @@ extern "C" int saga_fit_decode(const saga_decoder_t* d, const float* vars, float
     if ((rc = decoder_fwd(d, vars, w, B, st))) return rc;
     params_fwd_kernel<<<B, PK_THREADS, 0, st>>>(vars, w.x6, d->hand_comp, d->pose_mean, nullptr, nullptr, nullptr, nullptr, body_params,
                                                 0, d->n_pca, w.hdr);
+    SAGA_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- the parameter maps as a stand-alone operator (autograd callers: GraspMotion-Opt stage 2) --------------------------------
+struct ParamsWs { float *h1, *h2, *x6, *jac, *g_x6, *g_h, *g_z; size_t total; };
+static ParamsWs params_ws_carve(float* base, int hidden, int B) {
+    ParamsWs w;
+    size_t off = 0;
+    auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += (n + 63) / 64 * 64; return p; };
+    const size_t b = (size_t)B;
+    w.h1 = take(b * hidden); w.h2 = take(b * hidden); w.x6 = take(b * X6_LD); w.jac = take(b * (NB_MAX + 1) * 18);
+    w.g_x6 = take(b * X6_LD); w.g_h = take(b * hidden); w.g_z = take(b * 128);
+    w.total = off;
+    return w;
+}
+
+// grad rows: the latent columns come out of the decoder's backward (g_z), the pad columns are zero
+__global__ void params_grad_finish_kernel(const float* __restrict__ g_z, float* __restrict__ grad, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * VS) return;
+    const int b = i / VS, col = i - b * VS;
+    if (col < SAGA_VAR_HAND) grad[i] = g_z[(size_t)b * 128 + col];
+    else if (col >= SAGA_VAR_COUNT) grad[i] = 0.f;
+}
+
+extern "C" size_t saga_params_workspace_floats(const saga_decoder_t* d, int B) {
+    if (!d || B <= 0) return 0;
+    return params_ws_carve(nullptr, d->hidden, B).total;
+}
+
+extern "C" int saga_params_fwd(const saga_decoder_t* d, const float* vars, float* full_pose, float* shape, float* transl, int n_shape,
+                               float* ws, int B, void* stream) {
+    SAGA_CHECK_ARG(d && vars && full_pose && shape && transl && ws, "saga_params_fwd: null argument");
+    SAGA_CHECK_DEVICE(d, "saga_params_fwd");
+    SAGA_CHECK_ARG(B >= 0 && B <= 65535 && d->hidden <= 512 && n_shape >= 10, "saga_params_fwd: bad sizes B=%d n_shape=%d", B, n_shape);
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    ParamsWs p = params_ws_carve(ws, d->hidden, B);
+    FitWs w;
+    memset(&w, 0, sizeof(w));
+    w.h1 = p.h1; w.h2 = p.h2; w.x6 = p.x6;
+    Prof prof(SAGA_PROF_PARAMS_FWD, stream);
+    if (int rc = decoder_fwd(d, vars, w, B, st)) return rc;
+    params_fwd_kernel<<<B, PK_THREADS, 0, st>>>(vars, p.x6, d->hand_comp, d->pose_mean, full_pose, shape, transl, p.jac, nullptr, n_shape,
+                                                d->n_pca, nullptr);
+    SAGA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int saga_params_bwd(const saga_decoder_t* d, const float* vars, const float* g_full_pose, const float* g_shape,
+                               const float* g_transl, float* grad_vars, int n_shape, float* ws, int B, void* stream) {
+    SAGA_CHECK_ARG(d && vars && g_full_pose && grad_vars && ws, "saga_params_bwd: null argument");
+    SAGA_CHECK_DEVICE(d, "saga_params_bwd");
+    SAGA_CHECK_ARG(B >= 0 && B <= 65535 && d->hidden <= 512 && n_shape >= 10, "saga_params_bwd: bad sizes B=%d n_shape=%d", B, n_shape);
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    ParamsWs p = params_ws_carve(ws, d->hidden, B);     // h1 / h2 / jac: what saga_params_fwd left there for these vars
+    Prof prof(SAGA_PROF_PARAMS_BWD, stream);
+    params_bwd_kernel<<<B, PK_THREADS, 0, st>>>(vars, p.jac, d->hand_comp, g_full_pose, g_shape, g_transl, grad_vars, p.g_x6,
+                                                g_shape ? n_shape : 0, d->n_pca, RegCfg{0.f, 0.f, 0.f});
+    SAGA_LAUNCH_CHECK();
+    int rc;
+    if ((rc = saga_launch_gemm_nt(3, p.g_x6, X6_LD, d->w3t, X6_LD, p.g_h, d->hidden, nullptr, p.h2, B, d->hidden, X6_LD, st))) return rc;
+    if ((rc = saga_launch_gemm_nt(3, p.g_h, d->hidden, d->w2t, d->hidden, p.h2, d->hidden, nullptr, p.h1, B, d->hidden, d->hidden, st)))
+        return rc;
+    if ((rc = saga_launch_gemm_nt(0, p.h2, d->hidden, d->w1t, d->hidden, p.g_z, 128, nullptr, nullptr, B, 128, d->hidden, st))) return rc;
+    const int n = B * VS;
+    params_grad_finish_kernel<<<(n + 255) / 256, 256, 0, st>>>(p.g_z, grad_vars, B);
     SAGA_LAUNCH_CHECK();
     return 0;
 }

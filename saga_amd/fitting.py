@@ -61,6 +61,44 @@ def create_decoder(vposer, bm, device):
     return out
 
 
+class _ParamMaps(torch.autograd.Function):
+    """Packed variable rows [B,112] -> (full_pose [B,165], shape [B,n_shape], transl [B,3]) on ``saga_params_fwd/bwd``."""
+
+    @staticmethod
+    def forward(ctx, packed, decoder, n_shape):
+        _lib.require_device(packed)
+        pk = packed.detach().contiguous()
+        B, dev = pk.shape[0], pk.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        full_pose, shape, transl = torch.empty(B, 165, **f32), torch.empty(B, n_shape, **f32), torch.empty(B, 3, **f32)
+        ws = torch.empty(_lib.load().saga_params_workspace_floats(decoder, B), **f32)
+        _lib.call('saga_params_fwd', dev, decoder, _lib.ptr(pk), _lib.ptr(full_pose), _lib.ptr(shape), _lib.ptr(transl), n_shape,
+                  _lib.ptr(ws), B)
+        ctx.decoder, ctx.n_shape = decoder, n_shape
+        ctx.save_for_backward(pk, ws)
+        ctx.set_materialize_grads(False)
+        return full_pose, shape, transl
+
+    @staticmethod
+    def backward(ctx, g_pose, g_shape, g_transl):
+        pk, ws = ctx.saved_tensors
+        if g_pose is None and g_shape is None and g_transl is None:
+            return None, None, None
+        c = lambda g: None if g is None else g.contiguous()
+        g_pose = torch.zeros(pk.shape[0], 165, device=pk.device) if g_pose is None else g_pose.contiguous()
+        grad = torch.empty_like(pk)
+        _lib.call('saga_params_bwd', pk.device, ctx.decoder, _lib.ptr(pk), _lib.ptr(g_pose), _lib.ptr(c(g_shape)), _lib.ptr(c(g_transl)),
+                  _lib.ptr(grad), ctx.n_shape, _lib.ptr(ws), pk.shape[0])
+        return grad, None, None
+
+
+def param_maps(packed, decoder, n_shape=20):
+    """The optimiser-variable maps of the fitting ops as one operator: packed rows [B, ``_lib.VAR_STRIDE``] (``_lib.VAR_SLICES``:
+    VPoser latent 32 | hand PCA 48 | eyes 6 | betas 10 | transl 3 | 6D global orientation 6) -> (full_pose [B,165] with the pose
+    mean, shape [B,n_shape], transl [B,3]); ``decoder`` from :func:`create_decoder`.  Differentiable w.r.t. ``packed``."""
+    return _ParamMaps.apply(packed, decoder, int(n_shape))
+
+
 def loss_vertex_subset(faces, idx):
     """Ascending ids of the vertices one fitting iteration reads: the 143 markers, the right hand, the feet, and every corner
     of a face that touches a right-hand vertex (the hand's vertex normals sum over its incident faces)."""

@@ -22,8 +22,9 @@ import torch.optim as optim
 
 from . import _lib
 from . import smplx as _smplx
+from .smplx import lbs as _lbs
 from . import motion_losses as ml
-from .fitting import load_grasp_indices
+from .fitting import create_decoder, load_grasp_indices, param_maps
 from .geometry import point2point_signed, vertex_normals_subset
 from .rotations import cont6d_to_aa
 from .vposer import VPoserDecoder
@@ -85,13 +86,15 @@ class FittingOP:
     ``motion_losses``, the form the tests check it against), ``graph_stage1`` (default True: stage 1 replays one captured
     iteration, see ``fitting_stage1``), ``native_stage1`` (default True: every stage-1 iteration is one ``saga_fit_step`` call,
     see ``_fitting_stage1_native``; False: the autograd composition, replayed as a graph or eager), ``graph_stage2`` ('auto':
-    stage 2 replays one captured iteration when an iteration is launch-bound, i.e. up to 2,048 bodies; True / False force it)."""
+    stage 2 replays one captured iteration when an iteration is launch-bound, i.e. up to 2,048 bodies; True / False force it),
+    ``native_params`` (default True: stage 2 maps its variables to SMPL-X arguments with ``fitting.param_maps``, one operator,
+    instead of the torch VPoser MLP + 6D->aa + hand PCA; off with a ``body_smooth_loss`` hook, which takes the torch parameters)."""
 
     def __init__(self, fittingconfig):
         cfg = dict(T=61, gender='male', device='cuda', n_seq=1, start_t=30, init_lr_stage1=0.1, init_lr_stage2=0.01,
                    num_iter=[100, 300], body_model_path='./body_utils/body_models', vposer=None, smplx_kwargs={},
                    indices=None, body_smooth_loss=None, sparse_backward=True, reduced_forward=True, fused_terms=True,
-                   native_stage1=True, graph_stage1=True, graph_stage2='auto',
+                   native_stage1=True, graph_stage1=True, graph_stage2='auto', native_params=True,
                    stage1_weight_loss_rec_markers=1.0, stage1_weight_loss_vposer=0.02, stage1_weight_loss_shape=0.01,
                    stage1_weight_loss_hand=0.01,
                    stage2_weight_loss_rec_markers=0.1, stage2_weight_loss_end_markers_fit=10, stage2_weight_loss_vposer=0.02,
@@ -272,11 +275,17 @@ class FittingOP:
             h = self._s1_native = dict(bm=bm, tables=tables, decoder=dec, ws=torch.zeros(n, device=self.device))
         return h
 
+    def _decoder_handle(self):
+        """``saga_decoder_t*`` of the VPoser decoder and the body model's hand PCA (stage 2's ``param_maps``)."""
+        if self.__dict__.get('_decoder') is None:
+            self._decoder = create_decoder(self.vposer_model, self.smplx_model_batch, self.device)
+        return self._decoder
+
     def __del__(self):
         h = self.__dict__.get('_s1_native')
-        if h is not None:
+        for dec in ([h['decoder']] if h is not None else []) + ([self.__dict__['_decoder']] if self.__dict__.get('_decoder') else []):
             try:
-                _lib.load().saga_decoder_destroy(h['decoder'])
+                _lib.load().saga_decoder_destroy(dec)
             except Exception:
                 pass
 
@@ -368,28 +377,52 @@ class FittingOP:
                       normal_object, verts_object):
         """One evaluation of the stage-2 objective (``:356-409``) -> (total [S], dict of the weighted terms' raw values)."""
         S, T, start_t, w = self.n_seq, self.T, self.start_t, self
-        p = convert_to_3D_rot(torch.cat([self.transl_opt_T, self.rot_6d_opt_T, self.shape_T, self.other_params_opt_T],
-                                        dim=-1).reshape(S * T, -1))
         if self._picker is None:
             self._make_picker(rhand_verts)
         pk = self._picker
+        pp = None
+        if self.native_params and self.body_smooth_loss is None and hasattr(self.vposer_model, 'bodyprior_dec_fc1'):
+            # variables -> SMPL-X arguments as ONE operator (saga_params_fwd/bwd: VPoser MLP on the library's GEMM, 22 x (6D -> aa
+            # + Jacobian), hand PCA, pose mean) instead of ~60 PyTorch launches forward and as many backward
+            other = self.other_params_opt_T
+            packed = torch.cat([other.reshape(S * T, -1), other.new_zeros(S * T, 6), self.shape_T.reshape(S * T, -1),
+                                self.transl_opt_T.reshape(S * T, 3), self.rot_6d_opt_T.reshape(S * T, 6),
+                                other.new_zeros(S * T, _lib.VAR_STRIDE - 105)], dim=1)
+            smplx_args = param_maps(packed, self._decoder_handle(), self.smplx_model_batch.num_shape)
+            latent, hands = other[..., :32], other[..., 32:]
+
+            def bodies(bm, grad_ids=None):
+                shape, full_pose, transl = smplx_args[1], smplx_args[0], smplx_args[2]
+                if grad_ids is None:
+                    return _lbs.lbs(bm, shape, full_pose, transl)[0], None
+                sel, hs = bm._grad_subset(grad_ids, full_pose.device)
+                v, _, v_sel = _lbs.lbs_selected(bm, sel, hs, shape, full_pose, transl)
+                return v, v_sel
+        else:
+            p = convert_to_3D_rot(torch.cat([self.transl_opt_T, self.rot_6d_opt_T, self.shape_T, self.other_params_opt_T],
+                                            dim=-1).reshape(S * T, -1))
+            pp = p.reshape(S, T, -1)
+            latent, hands = pp[:, :, 16:48], pp[:, :, 48:]
+
+            def bodies(bm, grad_ids=None):
+                if grad_ids is None:
+                    return gen_body_mesh_v1(p, bm, self.vposer_model)[0], None
+                return gen_body_mesh_v1(p, bm, self.vposer_model, vertex_grad_ids=grad_ids)[0]
         bm, normal_ids = self.smplx_model_batch, (rhand_verts, self.markers_ids_143)
         if self._loss_model is not None:
             lm = self._loss_model
             bm, normal_ids = lm['bm'], (lm['rhand'], lm['markers_143'])
-            (verts, sub), _ = gen_body_mesh_v1(p, bm, self.vposer_model, vertex_grad_ids=lm['grad_rows'])
+            verts, sub = bodies(bm, lm['grad_rows'])
             verts, sub = verts.reshape(S, T, -1, 3), sub.reshape(S, T, -1, 3)
         elif self.sparse_backward and self.body_smooth_loss is None:
             # every vertex any term reads, as the differentiable output: the backward runs over those ~1,100 vertices only
             # (the full mesh is still evaluated -- the normals read it -- but carries no gradient)
-            (verts, sub), _ = gen_body_mesh_v1(p, self.smplx_model_batch, self.vposer_model, vertex_grad_ids=pk.union)
+            verts, sub = bodies(self.smplx_model_batch, pk.union)
             verts, sub = verts.reshape(S, T, -1, 3), sub.reshape(S, T, -1, 3)
         else:
-            verts, _ = gen_body_mesh_v1(p, self.smplx_model_batch, self.vposer_model)
-            verts = verts.reshape(S, T, -1, 3)
+            verts = bodies(self.smplx_model_batch)[0].reshape(S, T, -1, 3)
             sub = pk.gather(verts)                               # every vertex any term reads, gathered once
         picked = pk.pick(sub)                                    # every set the terms read: one kernel, one backward gather
-        pp = p.reshape(S, T, -1)
         if self.fused_terms:
             # the seven geometric terms as one operator over the picks and the two nearest-neighbour calls (:154-157)
             n_tail, O = T - start_t, verts_object.shape[-2]
@@ -411,8 +444,8 @@ class FittingOP:
                                  markers_rec_T, cache['mask'], markers_end_new, contact_lbl_rec, contact_object, contact_markers,
                                  normals[:, cache['n_rh']:])
             terms = dict(zip(ml.TERM_NAMES, t7.unbind(1)))
-            terms['vposer'] = (pp[:, :, 16:48] ** 2).mean(dim=(1, 2))
-            terms['hand'] = (pp[:, :, 48:] ** 2).mean(dim=(1, 2))
+            terms['vposer'] = (latent ** 2).mean(dim=(1, 2))
+            terms['hand'] = (hands ** 2).mean(dim=(1, 2))
             return self._total(terms, verts, pp)
         markers = picked['markers']
         mask = torch.ones(1, 1, markers.shape[2], 1, device=self.device)
@@ -429,8 +462,8 @@ class FittingOP:
         terms['hand_smooth'] = ml.hand_smooth_loss_seq(sub, start_t, pk.pos['rhand'], picked=picked)
         terms['collision'] = ml.collision_loss_seq(state)
         terms['hand_angle'] = ml.angle_loss_seq(state, start_t, T)
-        terms['vposer'] = (pp[:, :, 16:48] ** 2).mean(dim=(1, 2))
-        terms['hand'] = (pp[:, :, 48:] ** 2).mean(dim=(1, 2))
+        terms['vposer'] = (latent ** 2).mean(dim=(1, 2))
+        terms['hand'] = (hands ** 2).mean(dim=(1, 2))
         return self._total(terms, verts, pp)
 
     def _total(self, terms, verts, pp):

@@ -360,6 +360,68 @@ def test_motion_fused_terms_match_composition(body_model_dir):
         assert torch.equal(a, b)
 
 
+def test_param_maps_operator_matches_torch_maps(body_model_dir):
+    """fitting.param_maps (saga_params_fwd/bwd: VPoser MLP + 22 x 6D->aa + hand PCA + pose mean as one operator) against the
+    torch composition GraspMotion-Opt uses (convert_to_3D_rot + VPoser decode + the hand PCA inside the body model): SMPL-X
+    arguments within 5e-5, gradients of a random linear loss within 1e-4; and stage 2 with and without it: first-iteration
+    terms within 1e-5, gradients within 1e-4."""
+    from saga_amd import _lib
+    from saga_amd.fitting import create_decoder, param_maps
+    from saga_amd.motion_fitting import convert_to_3D_rot
+    from saga_amd.vposer import VPoserDecoder
+    B = 37
+    bm = make_hip_model(body_model_dir, B)
+    vp = VPoserDecoder(seed=0).cuda()
+    dec = create_decoder(vp, bm, torch.device('cuda', 0))
+    g = torch.Generator().manual_seed(4)
+    other = (0.5 * torch.randn(B, 80, generator=g)).cuda().requires_grad_(True)
+    transl = torch.randn(B, 3, generator=g).cuda().requires_grad_(True)
+    rot6 = torch.randn(B, 6, generator=g).cuda().requires_grad_(True)
+    betas = torch.randn(B, 10, generator=g).cuda()
+    w_pose, w_tr = torch.randn(B, 165, generator=g).cuda(), torch.randn(B, 3, generator=g).cuda()
+    packed = torch.cat([other, other.new_zeros(B, 6), betas, transl, rot6, other.new_zeros(B, _lib.VAR_STRIDE - 105)], dim=1)
+    full_pose, shape, tr = param_maps(packed, dec, 20)
+    ((full_pose * w_pose).sum() + (tr * w_tr).sum()).backward()
+    got = [t.grad.clone() for t in (other, transl, rot6)]
+    for t in (other, transl, rot6):
+        t.grad = None
+    p = convert_to_3D_rot(torch.cat([transl, rot6, betas, other], dim=-1))
+    body_pose = vp.decode(p[:, 16:48], output_type='aa').view(B, -1)
+    lh = torch.einsum('bi,ij->bj', p[:, 48:72], bm.left_hand_components)
+    rh = torch.einsum('bi,ij->bj', p[:, 72:], bm.right_hand_components)
+    ref_pose = torch.cat([p[:, 3:6], body_pose, p.new_zeros(B, 9), lh, rh], dim=1) + bm.pose_mean
+    ((ref_pose * w_pose).sum() + (p[:, :3] * w_tr).sum()).backward()
+    np.testing.assert_allclose(full_pose.detach().cpu().numpy(), ref_pose.detach().cpu().numpy(), atol=5e-5, rtol=0)    # (aa near pi)
+    assert torch.equal(shape[:, :10], betas) and shape[:, 10:].abs().max() == 0 and torch.equal(tr.detach(), transl.detach())
+    for a, t in zip(got, (other, transl, rot6)):
+        assert rel_err(a.cpu().numpy(), t.grad.cpu().numpy()) < 1e-4
+    _lib.load().saga_decoder_destroy(dec)
+    # inside stage 2
+    S, Tn, start_t = 2, 9, 4
+    idx, _, vposer, prob = _fit_problem(body_model_dir, S, Tn, start_t, seed=60)
+    transl = torch.tensor([0.0, 0.4, 1.0]) + 0.02 * torch.rand(S, Tn, 3, generator=g)
+    rot6 = torch.tensor([-1., 0, 0, 0, 0, 1]).expand(S, Tn, 6) + 0.05 * torch.randn(S, Tn, 6, generator=g)
+    other = 0.1 * torch.randn(S, Tn, 80, generator=g)
+    shape = prob['beta'][:, None].expand(S, Tn, 10).float().contiguous()
+    f = lambda a, *sh: torch.as_tensor(a).cuda().float().reshape(*sh)
+    res = {}
+    for native in (True, False):
+        op = _hip_op(body_model_dir, idx, vposer, prob, S, Tn, start_t, [0, 1])
+        op.native_params = native
+        op.init_param_T(transl, rot6, other, shape.numpy())
+        rh = torch.as_tensor(idx['rhand'], dtype=torch.long, device='cuda')
+        total, terms = op.stage2_losses(f(prob['markers_rec'], S, Tn, -1, 3), f(prob['markers_end'], S, -1, 3), rh,
+                                        f(prob['lbl'], S, Tn, 4), f(prob['c_obj'], S, -1), f(prob['c_mk'], S, -1),
+                                        f(prob['no'], S, Tn - start_t, 2048, 3), f(prob['vo'], S, Tn - start_t, 2048, 3))
+        total.sum().backward()
+        res[native] = (total.detach(), {k: v.detach() for k, v in terms.items()},
+                       [t.grad.clone() for t in (op.transl_opt_T, op.rot_6d_opt_T, op.other_params_opt_T)])
+    for k in res[False][1]:
+        np.testing.assert_allclose(res[True][1][k].cpu().numpy(), res[False][1][k].cpu().numpy(), rtol=1e-5, atol=1e-9, err_msg=k)
+    for a, b in zip(res[True][2], res[False][2]):
+        assert b.abs().max() > 0 and rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-4
+
+
 def test_motion_stage2_graph_replay_matches_eager(body_model_dir):
     """Stage 2 as a replayed HIP graph of one iteration (the default for small batches) against the eager loop: the same
     kernels; Adam in its capturable form.  First iteration equal to 1e-6, later totals within 5e-3, variables within 2e-3 after 6
