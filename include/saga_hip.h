@@ -101,6 +101,14 @@ int saga_smplx_fwd(const saga_model_t* m, const float* shape, const float* full_
                    float* vertices, float* joints,
                    float* feat, float* rot, float* jrest, float* chain, float* A, float* v_posed,
                    int B, void* stream);
+/* The same forward with the rows of a vertex subset written compact as well -- for callers whose loss reads those vertices only
+ * and whose backward runs on the subset model `sub` = saga_model_create_subset(...) (smplx forward(vertex_grad_ids=...) of the
+ * drop-in; no counterpart in the reference): v_posed_sel [B, saga_model_npad(sub)] in sub's layout (what saga_smplx_bwd(sub, ...)
+ * takes as v_posed) and vertices_sel [B, V(sub), 3] = the rows of `vertices`.  `m` may be a subset model of the same mesh too;
+ * every vertex of `sub` must then be a vertex of `m`. */
+int saga_smplx_fwd_selected(const saga_model_t* m, const saga_model_t* sub, const float* shape, const float* full_pose,
+                            const float* transl, float* vertices, float* joints, float* feat, float* rot, float* jrest,
+                            float* chain, float* A, float* v_posed, float* v_posed_sel, float* vertices_sel, int B, void* stream);
 
 /* SMPL-X backward (what loss.backward() drives through smplx at fittingop.py:383).
  *   g_vertices [B,V,3] or NULL; g_joints [B,55+E+L,3] or NULL (at least one non-NULL)

@@ -111,6 +111,7 @@ PROTOTYPES = {
     'saga_model_num_joints_out': (ctypes.c_int, [ctypes.c_void_p]),
     'saga_model_weight_nnz': (ctypes.c_int, [ctypes.c_void_p]),
     'saga_smplx_fwd': (ctypes.c_int, [ctypes.c_void_p] + [c_float_p] * 11 + [ctypes.c_int, c_stream]),
+    'saga_smplx_fwd_selected': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p] + [c_float_p] * 13 + [ctypes.c_int, c_stream]),
     'saga_smplx_bwd': (ctypes.c_int, [ctypes.c_void_p] + [c_float_p] * 15 + [ctypes.c_int, c_stream]),
     'saga_smplx_bwd_noalloc': (ctypes.c_int, [ctypes.c_void_p] + [c_float_p] * 11 + [ctypes.c_int, c_stream]),
     'saga_rodrigues_fwd': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, c_stream]),

@@ -26,7 +26,7 @@ int saga_grasp_loss_bwd_tagged(const saga_model_t* m, const saga_grasp_tables_t*
                                const int32_t* idx_o2h, float* g_verts, int B, int O, int32_t* zero_tag, int32_t tag, int compact, void* stream);
 int saga_smplx_fwd_sel(const saga_model_t* m, const saga_model_t* sub, const float* shape, const float* full_pose, const float* transl,
                        float* vertices, float* joints, float* feat, float* rot, float* jrest, float* chain, float* A, float* v_posed,
-                       float* sel_rows, int B, void* stream);
+                       float* sel_rows, int B, void* stream, float* sel_verts = nullptr);
 int saga_launch_hand_ring(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* verts, float* uniq_rows,
                           float* hand_normals, int B, void* stream);
 int saga_grasp_loss_fwd_pre(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* obj, const float* obj_normals,

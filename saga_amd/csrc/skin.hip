@@ -33,7 +33,9 @@ __global__ __launch_bounds__(SKIN_THREADS) void skin_fwd_kernel(const float* __r
                                                                 const float* __restrict__ transl, float* __restrict__ verts,
                                                                 int V, int Npad, int KW,
                                                                 const int32_t* __restrict__ sel_slot = nullptr,
-                                                                float* __restrict__ sel_rows = nullptr, int n_sel3 = 0, int npad_s = 0) {
+                                                                float* __restrict__ sel_rows = nullptr, int n_sel3 = 0, int npad_s = 0,
+                                                                const int32_t* __restrict__ parent_ids = nullptr,
+                                                                float* __restrict__ sel_verts = nullptr) {
     __shared__ __attribute__((aligned(16))) float sA[NJ * 12];
     const int b = blockIdx.y;
     const int vbase = blockIdx.x * (SKIN_THREADS * SKIN_VPT);
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(SKIN_THREADS) void skin_fwd_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < SKIN_VPT; ++i) {
         const int v = min(vbase + i * SKIN_THREADS + tid, V - 1);
-        if (SEL) slot[i] = sel_slot[v];
+        if (SEL) slot[i] = sel_slot[parent_ids ? parent_ids[v] : v];     // (this model may itself be a subset: full-mesh id first)
         typedef float f32x3_t __attribute__((ext_vector_type(3)));
         const f32x3_t pv = __builtin_nontemporal_load(reinterpret_cast<const f32x3_t*>(src + v * 3));   // one 12-B load, read once
         const float3 p3 = make_float3(pv.x, pv.y, pv.z);
@@ -102,6 +104,10 @@ __global__ __launch_bounds__(SKIN_THREADS) void skin_fwd_kernel(const float* __r
             typedef float f32x3_t __attribute__((ext_vector_type(3)));
             const f32x3_t oo = {o.x, o.y, o.z};
             __builtin_nontemporal_store(oo, reinterpret_cast<f32x3_t*>(dst + v * 3));   // one 12-B store
+        }
+        if (SEL && sel_verts && slot[i] >= 0) {      // the selected vertices again, compact [B, n_sel, 3]
+            float* r = sel_verts + ((size_t)b * (n_sel3 / 3) + slot[i]) * 3;
+            r[0] = o.x; r[1] = o.y; r[2] = o.z;
         }
     }
 }
@@ -677,17 +683,19 @@ __global__ __launch_bounds__(DS_THREADS, 4) void skin_bwd_sparse_kernel(
 }
 
 // sub (may be NULL): subset model over this mesh; its rows of v_posed are also written to sel_rows [B, sub->Npad]
+// m may itself be a subset model (of the same full mesh as sub: sub's vertices must all be vertices of m -- the caller's contract);
+// sel_verts (may be NULL): the selected rows of verts, compact
 int saga_launch_skin_fwd_sel(const saga_model* m, const saga_model* sub, const float* A, const float* v_posed, const float* transl,
-                             float* verts, float* sel_rows, int B, hipStream_t st) {
+                             float* verts, float* sel_rows, float* sel_verts, int B, hipStream_t st) {
     const int per_block = SKIN_THREADS * SKIN_VPT;
     dim3 grid((m->V + per_block - 1) / per_block, B);
-    SAGA_CHECK_ARG(sub && sub->full_slot && sub->VF == m->V && sel_rows, "skin_fwd_sel: not a subset model of this mesh");
+    SAGA_CHECK_ARG(sub && sub->full_slot && sub->VF == m->VF && sub->V <= m->V && sel_rows, "skin_fwd_sel: not a subset model of this mesh");
     if (m->KW == 4)
         skin_fwd_kernel<true, true><<<grid, SKIN_THREADS, 0, st>>>(A, v_posed, m->w_idx, m->w_val, transl, verts, m->V, m->Npad, m->KW,
-                                                                   sub->full_slot, sel_rows, sub->V * 3, sub->Npad);
+                                                                   sub->full_slot, sel_rows, sub->V * 3, sub->Npad, m->sel_ids, sel_verts);
     else
         skin_fwd_kernel<false, true><<<grid, SKIN_THREADS, 0, st>>>(A, v_posed, m->w_idx, m->w_val, transl, verts, m->V, m->Npad, m->KW,
-                                                                    sub->full_slot, sel_rows, sub->V * 3, sub->Npad);
+                                                                    sub->full_slot, sel_rows, sub->V * 3, sub->Npad, m->sel_ids, sel_verts);
     SAGA_LAUNCH_CHECK();
     return 0;
 }

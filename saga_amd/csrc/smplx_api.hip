@@ -12,7 +12,7 @@ int saga_blend_bwd_splitk(const saga_model* m);
 int saga_launch_skin_fwd(const saga_model* m, const float* A, const float* v_posed, const float* transl, float* verts, int B,
                          hipStream_t st);
 int saga_launch_skin_fwd_sel(const saga_model* m, const saga_model* sub, const float* A, const float* v_posed, const float* transl,
-                             float* verts, float* sel_rows, int B, hipStream_t st);
+                             float* verts, float* sel_rows, float* sel_verts, int B, hipStream_t st);
 int saga_launch_joints_fwd(const saga_model* m, const float* chain, const float* verts, const float* transl, float* joints, int B,
                            hipStream_t st);
 int saga_launch_joints_bwd(const saga_model* m, const float* g_joints, float* g_pj, float* g_jsum, float* gv, int B,
@@ -75,7 +75,7 @@ extern "C" int saga_profile_read(double* total_ms_host, int32_t* count_host) {
 // sub / sel_rows (both NULL for the plain forward): see saga_launch_skin_fwd_sel; used by saga_fit_step_sparse
 int saga_smplx_fwd_sel(const saga_model_t* m, const saga_model_t* sub, const float* shape, const float* full_pose, const float* transl,
                        float* vertices, float* joints, float* feat, float* rot, float* jrest, float* chain, float* A, float* v_posed,
-                       float* sel_rows, int B, void* stream);
+                       float* sel_rows, int B, void* stream, float* sel_verts = nullptr);
 
 extern "C" int saga_smplx_fwd(const saga_model_t* m, const float* shape, const float* full_pose, const float* transl,
                               float* vertices, float* joints, float* feat, float* rot, float* jrest, float* chain, float* A,
@@ -84,9 +84,23 @@ extern "C" int saga_smplx_fwd(const saga_model_t* m, const float* shape, const f
                               stream);
 }
 
+// The forward with the rows of a vertex subset written compact as well (for callers whose loss reads those vertices only and whose
+// backward runs on the subset model: smplx forward(vertex_grad_ids=...)): v_posed_sel [B, npad(sub)] in sub's layout (what
+// saga_smplx_bwd(sub, ...) takes as v_posed) and vertices_sel [B, V(sub), 3].  m may be a subset model too; sub's vertices must be
+// vertices of m.
+extern "C" int saga_smplx_fwd_selected(const saga_model_t* m, const saga_model_t* sub, const float* shape, const float* full_pose,
+                                       const float* transl, float* vertices, float* joints, float* feat, float* rot, float* jrest,
+                                       float* chain, float* A, float* v_posed, float* v_posed_sel, float* vertices_sel, int B,
+                                       void* stream) {
+    SAGA_CHECK_ARG(sub && v_posed_sel && vertices_sel, "saga_smplx_fwd_selected: null subset argument");
+    SAGA_CHECK_DEVICE(sub, "saga_smplx_fwd_selected (subset model)");
+    return saga_smplx_fwd_sel(m, sub, shape, full_pose, transl, vertices, joints, feat, rot, jrest, chain, A, v_posed, v_posed_sel, B,
+                              stream, vertices_sel);
+}
+
 int saga_smplx_fwd_sel(const saga_model_t* m, const saga_model_t* sub, const float* shape, const float* full_pose, const float* transl,
                        float* vertices, float* joints, float* feat, float* rot, float* jrest, float* chain, float* A, float* v_posed,
-                       float* sel_rows, int B, void* stream) {
+                       float* sel_rows, int B, void* stream, float* sel_verts) {
     SAGA_CHECK_ARG(m, "saga_smplx_fwd: null model");
     SAGA_CHECK_DEVICE(m, "saga_smplx_fwd");
     SAGA_CHECK_ARG(B >= 0 && B <= 65535, "saga_smplx_fwd: batch %d outside [0, 65535]", B);
@@ -99,7 +113,7 @@ int saga_smplx_fwd_sel(const saga_model_t* m, const saga_model_t* sub, const flo
     { PROF(SAGA_PROF_BLEND_FWD); if ((rc = saga_launch_blend_fwd(m, feat, v_posed, B, st))) return rc; }
     {
         PROF(SAGA_PROF_SKIN_FWD);
-        if ((rc = sub ? saga_launch_skin_fwd_sel(m, sub, A, v_posed, transl, vertices, sel_rows, B, st)
+        if ((rc = sub ? saga_launch_skin_fwd_sel(m, sub, A, v_posed, transl, vertices, sel_rows, sel_verts, B, st)
                       : saga_launch_skin_fwd(m, A, v_posed, transl, vertices, B, st)))
             return rc;
     }

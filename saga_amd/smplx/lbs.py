@@ -122,14 +122,13 @@ class _LBSSelected(torch.autograd.Function):
         chain = torch.empty(B, 55, 12, **f32)
         A = torch.empty(B, 55, 12, **f32)
         v_posed = torch.empty(B, npad, **f32)
-        _lib.call('saga_smplx_fwd', dev, h, _lib.ptr(shape), _lib.ptr(full_pose), _lib.ptr(transl), _lib.ptr(vertices),
-                                      _lib.ptr(joints), _lib.ptr(feat), _lib.ptr(rot), _lib.ptr(jrest), _lib.ptr(chain),
-                                      _lib.ptr(A), _lib.ptr(v_posed), B)
         U = sel.shape[0]
-        npad_s = lib.saga_model_npad(hs)
-        v_posed_s = torch.zeros(B, npad_s, **f32)                      # the subset model's layout: [B, Npad_s], pad = 0
-        v_posed_s[:, :3 * U] = v_posed[:, :3 * V].view(B, V, 3).index_select(1, sel).view(B, 3 * U)
-        vertices_sel = vertices.index_select(1, sel)
+        v_posed_s = torch.empty(B, lib.saga_model_npad(hs), **f32)     # the subset model's layout: [B, Npad_s], pad written 0
+        vertices_sel = torch.empty(B, U, 3, **f32)
+        # the skinning kernel writes the selected rows compact while it has them in registers (no gather passes)
+        _lib.call('saga_smplx_fwd_selected', dev, h, hs, _lib.ptr(shape), _lib.ptr(full_pose), _lib.ptr(transl), _lib.ptr(vertices),
+                  _lib.ptr(joints), _lib.ptr(feat), _lib.ptr(rot), _lib.ptr(jrest), _lib.ptr(chain), _lib.ptr(A), _lib.ptr(v_posed),
+                  _lib.ptr(v_posed_s), _lib.ptr(vertices_sel), B)
         ctx.model, ctx.subset = model, hs
         ctx.has_transl = transl is not None
         ctx.save_for_backward(full_pose, rot, jrest, chain, A, v_posed_s)
