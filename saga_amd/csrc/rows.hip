@@ -22,26 +22,25 @@ __global__ __launch_bounds__(PICK_THREADS) void pick_sets_fwd_kernel(const float
         const saga_pick_set_t& st = ps.s[k];
         if (t < st.t0) continue;
         float* o = st.out + ((size_t)s * (T - st.t0) + (t - st.t0)) * st.n * 3;
-        for (int e = blockIdx.x * PICK_THREADS + threadIdx.x; e < st.n * 3; e += gridDim.x * PICK_THREADS) {
-            const int i = e / 3, c = e - i * 3;
-            o[e] = sp[st.pos[i] * 3 + c];
-        }
+        typedef float f32x3_t __attribute__((ext_vector_type(3)));
+        for (int i = blockIdx.x * PICK_THREADS + threadIdx.x; i < st.n; i += gridDim.x * PICK_THREADS)       // one 12-B row per lane
+            *reinterpret_cast<f32x3_t*>(o + i * 3) = *reinterpret_cast<const f32x3_t*>(sp + st.pos[i] * 3);
     }
 }
 
 __global__ __launch_bounds__(PICK_THREADS) void pick_sets_bwd_kernel(PickSets ps, float* __restrict__ g_src, int T, int U) {
     const int frame = blockIdx.y, s = frame / T, t = frame - s * T;
     float* o = g_src + (size_t)frame * U * 3;
-    for (int e = blockIdx.x * PICK_THREADS + threadIdx.x; e < U * 3; e += gridDim.x * PICK_THREADS) {
-        const int u = e / 3, c = e - u * 3;
-        float acc = 0.f;
+    typedef float f32x3_t __attribute__((ext_vector_type(3)));
+    for (int u = blockIdx.x * PICK_THREADS + threadIdx.x; u < U; u += gridDim.x * PICK_THREADS) {         // one 12-B row per lane
+        f32x3_t acc = {0.f, 0.f, 0.f};
         for (int k = 0; k < ps.n; ++k) {
             const saga_pick_set_t& st = ps.s[k];
             if (t < st.t0 || !st.g_out) continue;
             const float* g = st.g_out + ((size_t)s * (T - st.t0) + (t - st.t0)) * st.n * 3;
-            for (int j = st.inv_ptr[u]; j < st.inv_ptr[u + 1]; ++j) acc += g[st.inv_idx[j] * 3 + c];
+            for (int j = st.inv_ptr[u]; j < st.inv_ptr[u + 1]; ++j) acc += *reinterpret_cast<const f32x3_t*>(g + st.inv_idx[j] * 3);
         }
-        o[e] = acc;
+        *reinterpret_cast<f32x3_t*>(o + u * 3) = acc;
     }
 }
 
@@ -66,7 +65,7 @@ extern "C" int saga_pick_sets_fwd(const float* src, const saga_pick_set_t* sets,
     if (S == 0) return 0;
     int n_max = 0;
     for (int k = 0; k < n_sets; ++k) n_max = std::max(n_max, sets[k].n);
-    dim3 grid(std::min(4, (n_max * 3 + PICK_THREADS - 1) / PICK_THREADS), S * T);
+    dim3 grid(std::min(4, (n_max + PICK_THREADS - 1) / PICK_THREADS), S * T);
     pick_sets_fwd_kernel<<<grid, PICK_THREADS, 0, (hipStream_t)stream>>>(src, ps, T, U);
     SAGA_LAUNCH_CHECK();
     return 0;
@@ -77,7 +76,7 @@ extern "C" int saga_pick_sets_bwd(const saga_pick_set_t* sets, int n_sets, float
     if (int rc = pick_check(sets, n_sets, S, T, U, false, ps, "saga_pick_sets_bwd")) return rc;
     SAGA_CHECK_ARG(g_src, "saga_pick_sets_bwd: null g_src");
     if (S == 0) return 0;
-    dim3 grid(std::min(4, (U * 3 + PICK_THREADS - 1) / PICK_THREADS), S * T);
+    dim3 grid(std::min(4, (U + PICK_THREADS - 1) / PICK_THREADS), S * T);
     pick_sets_bwd_kernel<<<grid, PICK_THREADS, 0, (hipStream_t)stream>>>(ps, g_src, T, U);
     SAGA_LAUNCH_CHECK();
     return 0;
