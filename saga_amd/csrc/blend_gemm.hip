@@ -26,6 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GEMM_NST_FWD 4      // LDS stages, forward
 #endif
 #define GEMM_NST_BWD 5      // LDS stages, backward (split-K)
+#define GEMM_SMALL_TILES 256 // launches of at most this many 128 x 128 tiles (less than one per CU) run 64 x 64 tiles instead
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -301,6 +302,18 @@ int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed
     // traffic of the launch 1.14 -> 0.81 GB, same bits -- but the launch is 0.8 % slower and the skinning forward, which then finds
     // nothing of v_posed in the Infinity Cache, 0.013 ms slower: 4.324 against 4.300 ms per iteration.  Off by default: time wins.
     static const int want_lepi = getenv("SAGA_GEMM_LEPI") ? atoi(getenv("SAGA_GEMM_LEPI")) : 0;
+    // Few tiles (small batches, vertex-subset models: the 256 x 79-vertex launches of GraspMotion-Opt stage 1 are 8 tiles): the
+    // launch is bound by the LATENCY of one tile's k-loop (32 k-steps x 2,048 MFMA cycles = 27 us for 128 x 128), so 64 x 64 tiles
+    // (a quarter of the cycles per k-step, four times the blocks) finish sooner: 39 -> ? us.  Same products in the same order:
+    // same bits (SAGA_GEMM_SMALL=0: always 128 x 128).
+    static const int want_small = getenv("SAGA_GEMM_SMALL") ? atoi(getenv("SAGA_GEMM_SMALL")) : 1;
+    if (want_small && !want_lepi && n_tiles <= GEMM_SMALL_TILES) {
+        const int tm = (B + 63) / 64, tn = m->Npad / 64;
+        gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD, 1><<<dim3(tm * tn), 256, 0, st>>>(feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template,
+                                                                                      nullptr, B, m->Npad, FEAT_K, FEAT_K, tm);
+        SAGA_LAUNCH_CHECK();
+        return 0;
+    }
     if (want_lepi) {
         grid.x = n_tiles;
         gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD, 2, true, true><<<grid, 256, 0, st>>>(feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template,
@@ -344,6 +357,14 @@ int saga_launch_blend_bwd(const saga_model* m, const float* g_vposed, float* sla
     dim3 grid(tiles_m * tiles_n, 1, splitk);
     static const int want_xcd = getenv("SAGA_GEMM_XCD") ? atoi(getenv("SAGA_GEMM_XCD")) : 1;     // SAGA_GEMM_XCD=0: plain tile order (A/B)
     const int xcd_map = (want_xcd && splitk % 8 == 0) ? 2 : 0;
+    static const int want_small = getenv("SAGA_GEMM_SMALL") ? atoi(getenv("SAGA_GEMM_SMALL")) : 1;
+    if (want_small && tiles_m * tiles_n * splitk <= GEMM_SMALL_TILES) {        // latency-bound launch: 64 x 64 tiles (see the forward)
+        const int tm = (B + 63) / 64, tn = FEAT_K / 64;
+        gemm_nt_f32_kernel<1, GEMM_BKT, GEMM_NST_BWD, 1><<<dim3(tm * tn, 1, splitk), 256, 0, st>>>(g_vposed, m->Npad, m->Bk, m->Npad, slabs, FEAT_K,
+                                                                                                 nullptr, nullptr, B, FEAT_K, m->Npad, kchunk, tm);
+        SAGA_LAUNCH_CHECK();
+        return 0;
+    }
     gemm_nt_f32_kernel<1, GEMM_BKT, GEMM_NST_BWD><<<grid, 256, 0, st>>>(g_vposed, m->Npad, m->Bk, m->Npad, slabs, FEAT_K, nullptr, nullptr, B, FEAT_K,
                                                 m->Npad, kchunk, tiles_m, xcd_map);
     SAGA_LAUNCH_CHECK();
