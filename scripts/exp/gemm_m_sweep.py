@@ -7,7 +7,7 @@ from saga_amd.synthetic import write_body_model
 tmp = tempfile.TemporaryDirectory(); write_body_model(tmp.name, gender='male', seed=7)
 nv = int(sys.argv[1]) if len(sys.argv) > 1 else 6604
 keep = np.sort(np.random.default_rng(0).choice(10475, nv, replace=False)) if nv < 10475 else None
-for B in (1024, 4096, 8192, 15616):
+for B in [int(x) for x in os.environ.get("SWEEP_B", "1024,4096,8192,15616").split(",")]:
     bm = smplx.create(tmp.name, model_type='smplx', gender='male', ext='npz', num_pca_comps=24, batch_size=B,
                       **({'vertex_subset': keep} if keep is not None else {})).cuda().eval()
     g = torch.Generator().manual_seed(1)
