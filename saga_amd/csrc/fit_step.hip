@@ -462,10 +462,11 @@ extern "C" size_t saga_params_workspace_floats(const saga_decoder_t* d, int B) {
 
 extern "C" int saga_params_fwd(const saga_decoder_t* d, const float* vars, float* full_pose, float* shape, float* transl, int n_shape,
                                float* ws, int B, void* stream) {
-    SAGA_CHECK_ARG(d && vars && full_pose && shape && transl && ws, "saga_params_fwd: null argument");
-    SAGA_CHECK_DEVICE(d, "saga_params_fwd");
+    SAGA_CHECK_ARG(d, "saga_params_fwd: null decoder");
     SAGA_CHECK_ARG(B >= 0 && B <= 65535 && d->hidden <= 512 && n_shape >= 10, "saga_params_fwd: bad sizes B=%d n_shape=%d", B, n_shape);
     if (B == 0) return 0;
+    SAGA_CHECK_ARG(vars && full_pose && shape && transl && ws, "saga_params_fwd: null argument");
+    SAGA_CHECK_DEVICE(d, "saga_params_fwd");
     hipStream_t st = (hipStream_t)stream;
     ParamsWs p = params_ws_carve(ws, d->hidden, B);
     FitWs w;
@@ -481,10 +482,11 @@ extern "C" int saga_params_fwd(const saga_decoder_t* d, const float* vars, float
 
 extern "C" int saga_params_bwd(const saga_decoder_t* d, const float* vars, const float* g_full_pose, const float* g_shape,
                                const float* g_transl, float* grad_vars, int n_shape, float* ws, int B, void* stream) {
-    SAGA_CHECK_ARG(d && vars && g_full_pose && grad_vars && ws, "saga_params_bwd: null argument");
-    SAGA_CHECK_DEVICE(d, "saga_params_bwd");
+    SAGA_CHECK_ARG(d, "saga_params_bwd: null decoder");
     SAGA_CHECK_ARG(B >= 0 && B <= 65535 && d->hidden <= 512 && n_shape >= 10, "saga_params_bwd: bad sizes B=%d n_shape=%d", B, n_shape);
     if (B == 0) return 0;
+    SAGA_CHECK_ARG(vars && g_full_pose && grad_vars && ws, "saga_params_bwd: null argument");
+    SAGA_CHECK_DEVICE(d, "saga_params_bwd");
     hipStream_t st = (hipStream_t)stream;
     ParamsWs p = params_ws_carve(ws, d->hidden, B);     // h1 / h2 / jac: what saga_params_fwd left there for these vars
     Prof prof(SAGA_PROF_PARAMS_BWD, stream);

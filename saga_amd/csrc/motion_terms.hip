@@ -294,6 +294,7 @@ extern "C" int saga_motion_terms_fwd(const saga_motion_terms_cfg_t* cfg, const f
                                      const float* palm_normals, float* terms, void* stream) {
     MtDims d;
     if (int rc = mt_dims(cfg, d, "saga_motion_terms_fwd")) return rc;
+    if (d.S == 0) return 0;
     SAGA_CHECK_ARG(markers && markers_rec && marker_mask && markers_end && feet && contact_lbl && hand_tail && o2h_signed &&
                        contact_object && h2o_marker && contact_markers && h2o_marker_vec && palm_normals && terms,
                    "saga_motion_terms_fwd: null argument");
@@ -315,6 +316,7 @@ extern "C" int saga_motion_terms_bwd(const saga_motion_terms_cfg_t* cfg, const f
                                      float* g_h2o_marker_vec, void* stream) {
     MtDims d;
     if (int rc = mt_dims(cfg, d, "saga_motion_terms_bwd")) return rc;
+    if (d.S == 0) return 0;
     SAGA_CHECK_ARG(markers && markers_rec && marker_mask && markers_end && feet && contact_lbl && hand_tail && o2h_signed &&
                        contact_object && h2o_marker && contact_markers && h2o_marker_vec && palm_normals && terms && g_terms &&
                        g_markers && g_feet && g_hand_tail && g_o2h_signed && g_h2o_marker && g_h2o_marker_vec,

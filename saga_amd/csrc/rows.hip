@@ -48,6 +48,7 @@ static int pick_check(const saga_pick_set_t* sets, int n_sets, int S, int T, int
     SAGA_CHECK_ARG(sets && n_sets > 0 && n_sets <= SAGA_PICK_MAX_SETS, "%s: 1..%d sets", what, SAGA_PICK_MAX_SETS);
     SAGA_CHECK_ARG(S >= 0 && T > 0 && U > 0 && (long long)S * T <= 65535, "%s: bad sizes S=%d T=%d U=%d (S*T <= 65535)", what, S, T, U);
     ps.n = n_sets;
+    if (S == 0) return 0;        // an empty batch: nothing to check the pointers of (empty tensors have none)
     for (int k = 0; k < n_sets; ++k) {
         const saga_pick_set_t& st = sets[k];
         SAGA_CHECK_ARG(st.n > 0 && st.t0 >= 0 && st.t0 < T, "%s: set %d has n=%d t0=%d (T=%d)", what, k, st.n, st.t0, T);
@@ -61,8 +62,8 @@ static int pick_check(const saga_pick_set_t* sets, int n_sets, int S, int T, int
 extern "C" int saga_pick_sets_fwd(const float* src, const saga_pick_set_t* sets, int n_sets, int S, int T, int U, void* stream) {
     PickSets ps;
     if (int rc = pick_check(sets, n_sets, S, T, U, true, ps, "saga_pick_sets_fwd")) return rc;
-    SAGA_CHECK_ARG(src, "saga_pick_sets_fwd: null src");
     if (S == 0) return 0;
+    SAGA_CHECK_ARG(src, "saga_pick_sets_fwd: null src");
     int n_max = 0;
     for (int k = 0; k < n_sets; ++k) n_max = std::max(n_max, sets[k].n);
     dim3 grid(std::min(4, (n_max + PICK_THREADS - 1) / PICK_THREADS), S * T);
@@ -74,8 +75,8 @@ extern "C" int saga_pick_sets_fwd(const float* src, const saga_pick_set_t* sets,
 extern "C" int saga_pick_sets_bwd(const saga_pick_set_t* sets, int n_sets, float* g_src, int S, int T, int U, void* stream) {
     PickSets ps;
     if (int rc = pick_check(sets, n_sets, S, T, U, false, ps, "saga_pick_sets_bwd")) return rc;
-    SAGA_CHECK_ARG(g_src, "saga_pick_sets_bwd: null g_src");
     if (S == 0) return 0;
+    SAGA_CHECK_ARG(g_src, "saga_pick_sets_bwd: null g_src");
     dim3 grid(std::min(4, (U + PICK_THREADS - 1) / PICK_THREADS), S * T);
     pick_sets_bwd_kernel<<<grid, PICK_THREADS, 0, (hipStream_t)stream>>>(ps, g_src, T, U);
     SAGA_LAUNCH_CHECK();

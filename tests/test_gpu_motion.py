@@ -130,6 +130,31 @@ def test_row_picker_matches_index_select():
         picker(torch.zeros(2, 3, U, 3).cuda())                        # set d starts at frame 3
 
 
+def test_round2_operators_accept_empty_batches(body_model_dir):
+    """Zero sequences / bodies are a no-op for the row picks, the stage-2 terms, the parameter maps and the windowed normals."""
+    from saga_amd import _lib
+    from saga_amd.fitting import create_decoder, param_maps
+    from saga_amd.geometry import RowPicker, point2point_signed, vertex_normals_subset
+    from saga_amd.vposer import VPoserDecoder
+    dev = torch.device('cuda', 0)
+    out = RowPicker({'a': torch.arange(5), 'b': (torch.tensor([1, 1, 3]), 2)}, 7)(torch.zeros(0, 4, 7, 3, device=dev, requires_grad=True))
+    assert out['a'].shape == (0, 4, 5, 3) and out['b'].shape == (0, 2, 3, 3)
+    (out['a'].sum() + out['b'].sum()).backward()
+    z = lambda *sh: torch.zeros(*sh, device=dev)
+    t = ml.motion_terms(z(0, 5, 79, 3), z(0, 5, 8, 3), [2, 2, 2, 2], z(0, 3, 778, 3), z(0, 2048), z(0, 143), z(0, 143, 3), z(0, 5, 79, 3),
+                        torch.ones(79, device=dev), z(0, 79, 3), z(0, 5, 4), z(0, 2048), z(0, 143), z(0, 22, 3))
+    assert t.shape == (0, 7)
+    bm = make_hip_model(body_model_dir, 1)
+    dec = create_decoder(VPoserDecoder(seed=0).cuda(), bm, dev)
+    fp, sh, tr = param_maps(z(0, _lib.VAR_STRIDE), dec, 20)
+    assert fp.shape == (0, 165) and sh.shape == (0, 20) and tr.shape == (0, 3)
+    _lib.load().saga_decoder_destroy(dec)
+    n = vertex_normals_subset(bm, z(0, 3, 10475, 3), torch.arange(4, dtype=torch.int32, device=dev), first_frame=1)
+    assert n.shape == (0, 4, 3)
+    o = point2point_signed(z(0, 5, 3), z(0, 9, 3), directions='y2x')
+    assert o[0].shape == (0, 9) and o[1] is None
+
+
 # ---- the two-stage driver (MotionFill/models/fittingop.py:283-428), S sequences per launch ------------------------------
 def _fit_problem(body_model_dir, S, Tn, start_t, seed=0):
     """Targets from smooth synthetic motions: 79 markers per frame, an object next to the right hand of the last frame."""
