@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "saga_common.h"
 
@@ -46,6 +47,52 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
     else static_assert(N == 0, "unsupported vmcnt");
 }
 
+// Fragment reads as inline asm.  hipcc treats every ds_read after an outstanding LDS-DMA as a possible alias of it and drains vmcnt(0)
+// first -- in a loop that is EVERY k-step (the DMA of the step before is still in flight), so the deep stage ring degenerates to
+// "wait for the youngest tile": the load latency of one tile had to fit into one k-step.  The asm reads are invisible to that rule;
+// the counted vmcnt wait + barrier at the top of the step is what orders them after the DMA that filled their stage, and the
+// lgkmcnt waits below (tied to the destination registers, so the MFMAs cannot move above them) order the MFMAs after the reads.
+template <int I, int N, class F>
+__device__ __forceinline__ void gemm_static_for(F&& f) {       // f(integral_constant<int, I>) for I..N-1: every index a constant
+    if constexpr (I < N) {                                      // (a plain unrolled loop left the accumulator array in scratch)
+        f(std::integral_constant<int, I>());
+        gemm_static_for<I + 1, N>(f);
+    }
+}
+typedef float gemm_f4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ gemm_f4 gemm_lds_read128(uint32_t addr) {
+    gemm_f4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void gemm_wait_lgkm(gemm_f4& a, gemm_f4& b, gemm_f4& c, gemm_f4& d) {
+    if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+    else static_assert(N == 0, "unsupported lgkmcnt");
+}
+template <int N>        // (every register once: a repeated "+v" operand is copied BEFORE the wait, i.e. before its read has landed)
+__device__ __forceinline__ void gemm_wait_lgkm(gemm_f4& a, gemm_f4& b) {
+    if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b)::"memory");
+    else static_assert(N == 0, "unsupported lgkmcnt");
+}
+
+#ifdef GEMM_EXP_TRACE      // investigation build only: per-block time stamps of the persistent forward launch (scripts/exp/gemm_trace.py)
+#define GEMM_TRACE_STRIDE 96
+__device__ unsigned long long gemm_trace_buf[1024 * GEMM_TRACE_STRIDE];
+extern "C" int saga_debug_gemm_trace(unsigned long long* host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gemm_trace_buf), n * sizeof(unsigned long long));
+}
+#define GEMM_STAMP(slot)                                                                                                  \
+    if (EPI == 0 && WT == 2 && threadIdx.x == 0 && n_tiles_x > (int)gridDim.x && (slot) < GEMM_TRACE_STRIDE)              \
+        gemm_trace_buf[blockIdx.x * GEMM_TRACE_STRIDE + (slot)] = clock64();
+#else
+#define GEMM_STAMP(slot)
+#endif
+
 // EPI 0: C[row][col] = acc + bias[col]           (C row stride ldc; bias may be NULL)
 // EPI 1: C[z][row][col] = acc                    (slab z = blockIdx.z, slab stride M*ldc)
 // EPI 2: C[row][col] = leaky_relu(acc + bias[col], 0.2)                    (VPoser decoder layers, fit_step.hip)
@@ -73,7 +120,20 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     // n_tiles_x > gridDim.x: a PERSISTENT launch -- a block walks the x tiles bx = blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x a
     // multiple of 8, so a block's tiles stay on its XCD's share of the ownership map below); 0: one tile per block
     if (n_tiles_x == 0) n_tiles_x = gridDim.x;
+#ifdef GEMM_EXP_STAGGER
+    // The two blocks of a CU start together and every tile takes the same time, so their prologues / epilogues (no MFMAs) coincide
+    // for the whole launch: the second half of the blocks (the second block of every CU) starts GEMM_EXP_STAGGER x 1,024 cycles late
+    if (n_tiles_x > (int)gridDim.x && blockIdx.x >= gridDim.x / 2)
+        for (int i = 0; i < GEMM_EXP_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
+#endif
+#ifdef GEMM_EXP_TRACE
+    if (EPI == 0 && WT == 2 && threadIdx.x == 0 && n_tiles_x > (int)gridDim.x)
+        gemm_trace_buf[blockIdx.x * GEMM_TRACE_STRIDE] =
+            (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32);
+    int trace_i = 0;
+#endif
     for (int bx = blockIdx.x; bx < n_tiles_x; bx += gridDim.x) {
+    GEMM_STAMP(1 + 6 * trace_i)
     if (bx != (int)blockIdx.x) __syncthreads();      // every wave has left the previous tile's last LDS stage
     // consecutive blocks walk M first so the (large, batch-shared) Bt tile stays hot in L2 while A is re-read
     int tile_m = bx % tiles_m;
@@ -103,7 +163,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     const int T = (k_end - k_begin) / BKT;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: the LDS-DMA targets become scalar arithmetic)
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
 
@@ -112,23 +172,28 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     auto swz = [](int row) { return BKT == 32 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
     // LDS-DMA source addresses: piece p = wave*PPW + j covers tile rows RPP*p ..; lane -> (row, slot) and fetches the
-    // 16-B k-chunk slot ^ swz(row) of that row.
-    const float* a_src[PPW];
-    const float* b_src[PPW];
+    // 16-B k-chunk slot ^ swz(row) of that row.  A uniform 64-bit base (the tile's first row at k_begin: scalar registers, moved on by
+    // scalar adds) plus a per-lane 32-bit byte offset that never changes: the transfer's address costs no vector instruction
+    // (an immediate offset would not do: the instruction adds it to the LDS address as well).
+    const char* a_base = reinterpret_cast<const char*>(A + (size_t)m0 * lda + k_begin);
+    const char* b_base = reinterpret_cast<const char*>(Bt + (size_t)n0 * ldb + k_begin);
+    uint32_t a_off[PPW], b_off[PPW];
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
         const int row = (wave * PPW + j) * RPP + lane / CPR;
         const int chunk = (lane % CPR) ^ swz(row);
-        a_src[j] = A + (size_t)min(m0 + row, M - 1) * lda + k_begin + chunk * 4;
-        b_src[j] = Bt + (size_t)min(n0 + row, N - 1) * ldb + k_begin + chunk * 4;
+        a_off[j] = ((uint32_t)min(row, M - 1 - m0) * (uint32_t)lda + chunk * 4) * 4u;
+        b_off[j] = ((uint32_t)min(row, N - 1 - n0) * (uint32_t)ldb + chunk * 4) * 4u;
     }
-    auto issue = [&](int stage, int koff) {
-        float* sa = smem + stage * (2 * TILE_FLOATS) + wave * (PPW * 256);
+    // LDS-DMA of the k-tile at byte offset koff of the bases, into stage STG (LDS target: scalar arithmetic, wave is uniform)
+    auto issue = [&](auto stg, int koff) __attribute__((always_inline)) {
+        constexpr int STG = decltype(stg)::value;
+        float* sa = smem + STG * (2 * TILE_FLOATS) + wave * (PPW * 256);
         float* sb = sa + TILE_FLOATS;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[j] + koff), (lds_ptr_t)(sa + j * 256), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b_src[j] + koff), (lds_ptr_t)(sb + j * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_base + koff + a_off[j]), (lds_ptr_t)(sa + j * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b_base + koff + b_off[j]), (lds_ptr_t)(sb + j * 256), 16, 0, 0);
         }
     };
 
@@ -140,57 +205,87 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fragment read offsets (floats): row * BKT + ((2g + half) ^ swz(row)) * 4; swz(row) depends on l31 only
+    // fragment read addresses (LDS bytes) in stage 0, per k-group: row * BKT + ((2g + half) ^ swz(row)) * 4; swz(row) depends on l31
+    // only.  The stage and the second 32-row tile are immediate offsets of the reads (16 bits: a second base from stage HI_STG on).
+    static_assert(BKT == 16, "the fragment reads are written for two k-groups per tile");
+    constexpr int STAGE_BYTES = 2 * TILE_FLOATS * 4;
+    constexpr int HI_STG = (65535 - TILE_FLOATS * 4 - 32 * BKT * 4) / STAGE_BYTES + 1;      // first stage the 16-bit offset cannot reach
     const int fsw = swz(l31);
-    const int a_row = (wm * 32 * WT + l31) * BKT, b_row = (wn * 32 * WT + l31) * BKT;
+    uint32_t fa[2][2], fb[2][2];        // [base: stage 0 / stage HI_STG][k-group]
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int koff = ((2 * g + half) ^ fsw) * 4;
+        fa[0][g] = (uint32_t)(uintptr_t)(lds_ptr_t)(smem + (wm * 32 * WT + l31) * BKT + koff);
+        fb[0][g] = (uint32_t)(uintptr_t)(lds_ptr_t)(smem + TILE_FLOATS + (wn * 32 * WT + l31) * BKT + koff);
+        fa[1][g] = fa[0][g] + HI_STG * STAGE_BYTES;
+        fb[1][g] = fb[0][g] + HI_STG * STAGE_BYTES;
+    }
 
+    gemm_static_for<0, NST - 1>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int S = decltype(sc)::value;
+        if (S < T) issue(sc, S * BKT * 4);
+    });
+    // The k-loop, NST steps per trip so that a step's stage is a constant.  Per step and wave: one counted wait, one barrier, 4 WT
+    // fragment reads, 2 PPW LDS-DMA instructions and 32 (WT 2) MFMAs -- and no vector arithmetic: the co-resident block's wave on
+    // this SIMD is inside an MFMA burst most of the time, and whatever vector instruction this wave issues meanwhile waits for a slot
+    // between two of its MFMAs (64 cycles each; measured: scripts/ab/store_pattern_ab.hip)
+    for (int t0 = 0; t0 < T; t0 += NST) {
+        gemm_static_for<0, NST>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int U = decltype(uc)::value;
+            const int t = t0 + U;
+            if (t < T) {
+                // tile t has landed once at most the NST-2 younger tiles are outstanding (fewer near the tail: drain)
+                if (NST > 2 && t + NST - 2 < T) gemm_wait_vmcnt<(NST - 2) * 2 * PPW>();
+                else gemm_wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();       // everyone's pieces have; everyone is done reading stage (t-1) % NST
+#ifdef GEMM_EXP_TRACE
+                if (t == 0) { GEMM_STAMP(2 + 6 * trace_i) }
+#endif
+                // fragment reads as asm (see gemm_lds_read128), all of them before the LDS-DMA of a later tile
+                constexpr int HB = U >= HI_STG ? 1 : 0, SOFF = (U - HB * HI_STG) * STAGE_BYTES;
+                gemm_f4 af[2][WT], bf[2][WT];
 #pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-        if (s < T) issue(s, s * BKT);
-    for (int t = 0; t < T; ++t) {
-        // tile t has landed once at most the NST-2 younger tiles are outstanding (fewer near the tail: drain)
-        if (NST > 2 && t + NST - 2 < T) gemm_wait_vmcnt<(NST - 2) * 2 * PPW>();
-        else gemm_wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();       // everyone's pieces have; everyone is done reading stage (t-1) % NST
-        const float* As = smem + (t % NST) * (2 * TILE_FLOATS);
-        const float* Bs = As + TILE_FLOATS;
-        // all fragment reads of this k-tile first, THEN the LDS-DMA of a later tile: hipcc waits vmcnt(0) before any
-        // ds_read that follows an outstanding LDS-DMA in program order, which would serialise the prefetch with the MFMAs
-        float4 af[BKT / 8][WT], bf[BKT / 8][WT];
-#pragma unroll
-        for (int g = 0; g < BKT / 8; ++g) {
-            const int koff = ((2 * g + half) ^ fsw) * 4;
-#pragma unroll
-            for (int u = 0; u < WT; ++u) {
-                af[g][u] = *reinterpret_cast<const float4*>(As + a_row + u * 32 * BKT + koff);
-                bf[g][u] = *reinterpret_cast<const float4*>(Bs + b_row + u * 32 * BKT + koff);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + NST - 1 < T) issue((t + NST - 1) % NST, (t + NST - 1) * BKT);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < BKT / 8; ++g) {
-#pragma unroll
-            for (int mt = 0; mt < WT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < WT; ++nt) {
-                    if (TRS) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].x, af[g][mt].x, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].y, af[g][mt].y, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].z, af[g][mt].z, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].w, af[g][mt].w, acc[mt][nt], 0, 0, 0);
-                    } else {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].x, bf[g][nt].x, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].y, bf[g][nt].y, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].z, bf[g][nt].z, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].w, bf[g][nt].w, acc[mt][nt], 0, 0, 0);
-                    }
+                for (int g = 0; g < 2; ++g) {
+                    af[g][0] = gemm_lds_read128<SOFF>(fa[HB][g]);
+                    if constexpr (WT == 2) af[g][1] = gemm_lds_read128<SOFF + 32 * BKT * 4>(fa[HB][g]);
+                    bf[g][0] = gemm_lds_read128<SOFF>(fb[HB][g]);
+                    if constexpr (WT == 2) bf[g][1] = gemm_lds_read128<SOFF + 32 * BKT * 4>(fb[HB][g]);
                 }
-        }
+                if (t + NST - 1 < T) issue(std::integral_constant<int, (U + NST - 1) % NST>(), (t + NST - 1) * BKT * 4);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    // LDS returns in order: group g's 2 WT reads are back once at most the later groups' are outstanding
+                    if (g == 1) __builtin_amdgcn_sched_barrier(0);      // (keeps group 1's wait behind group 0's MFMAs)
+                    if constexpr (WT == 2) {
+                        if (g == 0) gemm_wait_lgkm<4>(af[0][0], af[0][1], bf[0][0], bf[0][1]);
+                        else gemm_wait_lgkm<0>(af[1][0], af[1][1], bf[1][0], bf[1][1]);
+                    } else {
+                        if (g == 0) gemm_wait_lgkm<2>(af[0][0], bf[0][0]);
+                        else gemm_wait_lgkm<0>(af[1][0], bf[1][0]);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < WT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < WT; ++nt) {
+                            if (TRS) {
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].x, af[g][mt].x, acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].y, af[g][mt].y, acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].z, af[g][mt].z, acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].w, af[g][mt].w, acc[mt][nt], 0, 0, 0);
+                            } else {
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].x, bf[g][nt].x, acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].y, bf[g][nt].y, acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].z, bf[g][nt].z, acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mt].w, bf[g][nt].w, acc[mt][nt], 0, 0, 0);
+                            }
+                        }
+                }
+            }
+        });
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    GEMM_STAMP(3 + 6 * trace_i)
     float* Cz = C;
     if (EPI == 1) Cz += (size_t)slab * M * ldc;
     const bool full = (m0 + TBM <= M);       // N is always a multiple of BN here (Npad / 512)
@@ -225,21 +320,48 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
         continue;
     }
     if (TRS) {
-        // transposed tiles: row = lane&31, col = (r&3) + 8*(r>>2) + 4*(lane>>5): one 16-B store per register quad
+        // transposed tiles: row = lane&31, col = (r&3) + 8*(r>>2) + 4*(lane>>5): one 16-B store per register quad.  One address per
+        // 32-row tile, the quads at immediate offsets -- the epilogue is vector instructions the co-resident block's MFMA burst
+        // starves, so it is kept to the 16 WT adds of the bias and the stores (N is a multiple of the tile width for every caller).
+        // Everything the epilogue READS (bias quads: shared by the row tiles; EPI 3: the aux quads) is fetched before the first
+        // store: stores count in vmcnt, so a load issued between them would make its wait drain every store before it.
+        const int colw = n0 + wn * 32 * WT + 4 * half;
+        float4 bq[WT][4];
+        if ((EPI == 0 || EPI == 2) && bias) {
+            const float* bp = bias + colw;
+#pragma unroll
+            for (int nt = 0; nt < WT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bq[nt][q] = *reinterpret_cast<const float4*>(bp + nt * 32 + 8 * q);
+        }
+        float4 xq[EPI == 3 ? WT : 1][EPI == 3 ? WT : 1][4];
+        if (EPI == 3) {
+#pragma unroll
+            for (int mt = 0; mt < WT; ++mt) {
+                const float* xp = aux + (size_t)min(m0 + wm * 32 * WT + mt * 32 + l31, M - 1) * ldc + colw;
+#pragma unroll
+                for (int nt = 0; nt < WT; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xq[EPI == 3 ? mt : 0][EPI == 3 ? nt : 0][q] = *reinterpret_cast<const float4*>(xp + nt * 32 + 8 * q);
+            }
+        }
+#ifdef GEMM_EXP_TRACE
+        GEMM_STAMP(4 + 6 * trace_i)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GEMM_STAMP(5 + 6 * trace_i)
+#endif
 #pragma unroll
         for (int mt = 0; mt < WT; ++mt) {
             const int row = m0 + wm * 32 * WT + mt * 32 + l31;
             if (!full && row >= M) continue;
+            float* cp = Cz + (size_t)row * ldc + colw;
 #pragma unroll
             for (int nt = 0; nt < WT; ++nt) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int col = n0 + wn * 32 * WT + nt * 32 + 8 * q + 4 * half;
-                    if (col >= N) continue;
-                    const size_t off = (size_t)row * ldc + col;
                     float4 v = make_float4(acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]);
                     if ((EPI == 0 || EPI == 2) && bias) {
-                        const float4 bv = *reinterpret_cast<const float4*>(bias + col);
+                        const float4 bv = bq[nt][q];
                         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                     }
                     if (EPI == 2) {
@@ -247,17 +369,21 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
                         v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w;
                     }
                     if (EPI == 3) {
-                        const float4 x = *reinterpret_cast<const float4*>(aux + off);
+                        const float4 x = xq[EPI == 3 ? mt : 0][EPI == 3 ? nt : 0][q];
                         v.x = x.x > 0.f ? v.x : 0.2f * v.x; v.y = x.y > 0.f ? v.y : 0.2f * v.y;
                         v.z = x.z > 0.f ? v.z : 0.2f * v.z; v.w = x.w > 0.f ? v.w : 0.2f * v.w;
                     }
 #ifdef GEMM_EXP_NO_STORE        // timing experiment: what the epilogue's stores cost (wrong results)
                     if (v.x == 123.456f)
 #endif
-                    *reinterpret_cast<float4*>(Cz + off) = v;
+                    *reinterpret_cast<float4*>(cp + nt * 32 + 8 * q) = v;
                 }
             }
         }
+#ifdef GEMM_EXP_TRACE
+        GEMM_STAMP(6 + 6 * trace_i)
+        ++trace_i;
+#endif
         continue;
     }
 #pragma unroll
@@ -291,6 +417,321 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     }       // tiles of this block
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The blend contraction as ONE wave per SIMD (one 4-wave block per CU, persistent).  Measured on MI355X (scripts/ab/
+// mfma_share_ab.hip, store_pattern_ab.hip, scripts/exp/gemm_trace.py): two waves share a SIMD's matrix pipe perfectly as long as
+// both only issue MFMAs, but whatever else one of them has to issue -- the 16 stores of an epilogue, the address arithmetic of
+// its LDS-DMA -- crawls while its partner is inside an MFMA burst (an epilogue of 16 stores took 25-55 k cycles against 700
+// alone), and the partner does not make up for it: two blocks per CU lose 15-19 % of the matrix pipe, one block per CU with
+// nothing but MFMAs and stores runs at 99 %.  So this kernel gives each SIMD a single wave that hides everything in the shadow of
+// its own MFMAs (an MFMA occupies the pipe for 64 cycles, the wave is free to issue ~10 other instructions meanwhile):
+//   * the fragments of k-step s+1 are read from LDS into a second register set between the two MFMA groups of step s;
+//   * the LDS-DMA of step s+NST is issued there too, into the stage the block has just finished reading: NST-1 steps of latency
+//     cover; the stream of k-steps runs ACROSS tiles, so a tile's first operands are in flight during the previous tile's last steps;
+//   * the epilogue of a tile (accumulators + bias -> 16 stores per wave) runs at the top of the next tile's first step; the bias
+//     quads of a tile are fetched a whole tile ahead by asm loads the compiler does not wait for; vmcnt is counted by hand
+//     (in-order: DMA groups of 4, an epilogue's 16 stores + 8 bias loads).
+// Same products in the same order as gemm_nt_f32_kernel: bit-identical results (tests/test_gpu_smplx.py).
+#ifndef GEMM1W_NST
+#define GEMM1W_NST 6
+#endif
+#define GEMM1W_MAX_TILES 1024      // tiles per block the LDS tile table holds (12 KB)
+#define GEMM1W_LDS_BYTES (GEMM1W_NST * 2 * 128 * 16 * 4 + GEMM1W_MAX_TILES * 12)
+struct gemm_frag { gemm_f4 a[2][2], b[2][2]; };       // [k-group][32-row tile] of the wave's 64 x 64 tile
+template <int N>
+__device__ __forceinline__ void gemm_wait_vm() {
+    static_assert(N >= 0 && N <= 63, "vmcnt");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int EPI, int NST>
+__global__ __launch_bounds__(256, 1) void gemm_nt_f32_1w_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bt,
+                                                                int ldb, float* __restrict__ C, int ldc,
+                                                                const float* __restrict__ bias, int M, int N, int K, int kchunk,
+                                                                int tiles_m, int xcd_map, int per, int n_virtual) {
+    constexpr int BKT = 16, TILE_FLOATS = 128 * BKT, STAGE = 2 * TILE_FLOATS;
+    constexpr int EXTRA = EPI == 0 ? 24 : 16;       // vector-memory operations an epilogue puts into the in-order stream
+    extern __shared__ __attribute__((aligned(1024))) float smem1w[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int T = kchunk / BKT;
+    if ((int)blockIdx.x >= n_virtual) return;
+    const int n_my = (n_virtual - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+    const int total = n_my * T;
+
+    // virtual tile id -> (m0, n0, slab): the ownership maps of gemm_nt_f32_kernel (gridDim.x a multiple of 8: v & 7 = this block's XCD)
+    auto coords = [&](int v, int& m0, int& n0, int& slab) __attribute__((always_inline)) {
+        const int z = v / per, bx = v - z * per;
+        int tile_m = bx % tiles_m, tile_n = bx / tiles_m;
+        slab = z;
+        if (xcd_map == 2) {
+            const int x = v & 7, i = v >> 3;
+            slab = x + 8 * (i / per);
+            const int t = i % per, tiles_n = per / tiles_m;
+            tile_n = t % tiles_n;
+            tile_m = t / tiles_n;
+        } else if (xcd_map) {
+            const int x = bx & 7, i = bx >> 3;
+            const int mq = tiles_m >> 2, nh = (per / tiles_m) >> 1;
+            tile_m = (x & 3) * mq + i % mq;
+            tile_n = (x >> 2) * nh + i / mq;
+        }
+        m0 = tile_m * 128;
+        n0 = tile_n * 128;
+    };
+
+    // the block's tiles (m0, n0, slab), worked out once: the ownership maps divide by run-time numbers, and a wave alone on its SIMD
+    // has no partner to hide ~20 scalar instructions per division behind (they sat between two MFMAs of the steady-state loop)
+    int* tile_tab = reinterpret_cast<int*>(smem1w + NST * STAGE);
+    for (int i = tid; i < n_my; i += 256) {
+        int m0, n0, slab;
+        coords((int)blockIdx.x + i * (int)gridDim.x, m0, n0, slab);
+        tile_tab[3 * i] = m0; tile_tab[3 * i + 1] = n0; tile_tab[3 * i + 2] = slab;
+    }
+    __syncthreads();
+    auto tile_at = [&](int i, int& m0, int& n0, int& slab) __attribute__((always_inline)) {
+        m0 = __builtin_amdgcn_readfirstlane(tile_tab[3 * i]);
+        n0 = __builtin_amdgcn_readfirstlane(tile_tab[3 * i + 1]);
+        slab = __builtin_amdgcn_readfirstlane(tile_tab[3 * i + 2]);
+    };
+
+    // ---- issue side: LDS-DMA of global k-step gi (tile number i_v of this block, k-step i_t of it) into stage st_i = gi % NST
+    const float* a_src[2];
+    const float* b_src[2];
+    int i_v = 0, i_t = 0, gi = 0, st_i = 0;
+    auto issue_tile = [&](int v) __attribute__((always_inline)) {
+        int m0, n0, slab;
+        tile_at(v, m0, n0, slab);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (wave * 2 + j) * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+            a_src[j] = A + (size_t)min(m0 + row, M - 1) * lda + (size_t)slab * kchunk + chunk * 4;
+            b_src[j] = Bt + (size_t)min(n0 + row, N - 1) * ldb + (size_t)slab * kchunk + chunk * 4;
+        }
+    };
+    // one k-step's LDS-DMA in two halves (j = 0, 1: the wave's two 1-KiB pieces of each operand tile), then the bookkeeping
+    auto issue_half = [&](int j) __attribute__((always_inline)) {
+        float* sa = smem1w + st_i * STAGE + wave * 512;
+        float* sb = sa + TILE_FLOATS;
+        const int koff = i_t * BKT;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[j] + koff), (lds_ptr_t)(sa + j * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b_src[j] + koff), (lds_ptr_t)(sb + j * 256), 16, 0, 0);
+    };
+    auto issue_done = [&]() __attribute__((always_inline)) {
+        ++gi;
+        if (++st_i == NST) st_i = 0;
+        if (__builtin_expect(++i_t == T, 0)) {
+            i_t = 0;
+            ++i_v;
+            if (gi < total) issue_tile(i_v);
+        }
+    };
+    auto issue = [&]() __attribute__((always_inline)) { issue_half(0); issue_half(1); issue_done(); };
+
+    // ---- consume side
+    const int fsw = (l31 >> 2) & 3;
+    uint32_t fa[2], fb[2];          // LDS byte addresses of the wave's fragments in stage 0, per k-group
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int koff = ((2 * g + half) ^ fsw) * 4;
+        fa[g] = (uint32_t)(uintptr_t)(lds_ptr_t)(smem1w + (wm * 64 + l31) * BKT + koff);
+        fb[g] = (uint32_t)(uintptr_t)(lds_ptr_t)(smem1w + TILE_FLOATS + (wn * 64 + l31) * BKT + koff);
+    }
+    // fragment reads in four pieces (interleaved with the MFMAs below): piece p = (k-group p >> 1, operand p & 1)
+    auto read_piece = [&](gemm_frag& f, uint32_t so, int p) __attribute__((always_inline)) {
+        const int g = p >> 1;
+        if ((p & 1) == 0) {
+            f.a[g][0] = gemm_lds_read128<0>(fa[g] + so);
+            f.a[g][1] = gemm_lds_read128<32 * BKT * 4>(fa[g] + so);
+        } else {
+            f.b[g][0] = gemm_lds_read128<0>(fb[g] + so);
+            f.b[g][1] = gemm_lds_read128<32 * BKT * 4>(fb[g] + so);
+        }
+    };
+    auto read_frags = [&](gemm_frag& f, int stage) __attribute__((always_inline)) {
+        const uint32_t so = (uint32_t)stage * (STAGE * 4);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) read_piece(f, so, p);
+    };
+    auto frags_landed = [&](gemm_frag& f) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.a[1][0]), "+v"(f.a[1][1]),
+                       "+v"(f.b[1][0]), "+v"(f.b[1][1])::"memory");
+    };
+    gemm_f4 bq[2][4];               // bias quads of the tile being multiplied (EPI 0)
+    auto load_bias = [&](int n0) __attribute__((always_inline)) {
+        if (EPI != 0) return;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float* p = bias + n0 + wn * 64 + nt * 32 + 8 * q + 4 * half;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[nt][q]) : "v"(p) : "memory");
+            }
+    };
+    f32x16 acc[2][2];
+    // accumulators (+ bias) -> C; returns whether it issued exactly its 16 stores per lane-active wave (whole tile)
+    auto epilogue = [&](int v) __attribute__((always_inline)) -> bool {
+        int m0, n0, slab;
+        tile_at(v, m0, n0, slab);
+        float* Cz = C;
+        if (EPI == 1) Cz += (size_t)slab * M * ldc;
+        const bool full = m0 + 128 <= M;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int row = m0 + wm * 64 + mt * 32 + l31;
+            if (!full && row >= M) continue;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = n0 + wn * 64 + nt * 32 + 8 * q + 4 * half;
+                    float4 o = make_float4(acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]);
+                    if (EPI == 0) { o.x += bq[nt][q].x; o.y += bq[nt][q].y; o.z += bq[nt][q].z; o.w += bq[nt][q].w; }
+#ifdef GEMM_EXP_NO_STORE
+                    if (o.x == 123.456f)
+#endif
+                    *reinterpret_cast<float4*>(Cz + (size_t)row * ldc + col) = o;
+                }
+        }
+#ifdef GEMM_EXP_NO_STORE
+        return false;
+#endif
+        return full;
+    };
+
+    // ---- prologue: bias of the first tile, NST k-steps in flight, fragments of step 0
+    int c_v = 0, c_t = 0, st_c = 1;         // tile number / k-step being multiplied; stage of the NEXT step
+    bool counted = false;                   // the current tile began with a whole epilogue: EXTRA operations sit in the vmcnt stream
+    {
+        int m0, n0, slab;
+        tile_at(c_v, m0, n0, slab);
+        load_bias(n0);
+    }
+    issue_tile(i_v);
+    for (int s = 0; s < NST && s < total; ++s) issue();
+    if (total > NST - 1) gemm_wait_vm<(NST - 1) * 4>(); else gemm_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    gemm_frag F0, F1;
+    read_frags(F0, 0);
+#ifdef GEMM_EXP_NO_READS
+    read_frags(F1, 0);
+#endif
+
+    // MFMA i of a k-step (i = 0..31): k-group i >> 4, k-value (i >> 2) & 3, accumulator i & 3 -- round-robin over the four accumulators
+    // (a wave alone on its SIMD must not issue an MFMA that depends on the one before it); every accumulator still sums its k in
+    // ascending order: the bits of gemm_nt_f32_kernel
+    // `first`: the first k-step of a tile -- its first four MFMAs take the constant 0 as their C operand, so the accumulators are never
+    // written by anything but an MFMA (they stay in the AGPR file, which nothing else in the loop touches: see the Makefile note)
+    auto mfma1 = [&](const gemm_frag& f, auto ic, auto first) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int g = i >> 4, kk = (i >> 2) & 3, mt = (i >> 1) & 1, nt = i & 1;
+        if constexpr (decltype(first)::value && i < 4) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b[g][nt][kk], f.a[g][mt][kk], zero, 0, 0, 0);
+        } else {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b[g][nt][kk], f.a[g][mt][kk], acc[mt][nt], 0, 0, 0);
+        }
+    };
+    // One k-step: global step g multiplies the fragments in `cur` and fetches those of step g + 1 into `nxt`.  An MFMA occupies the
+    // pipe for 64 cycles and the wave issues in order, so whatever stands between two MFMAs must fit into those 64 cycles: the ~45
+    // other instructions of a step are dealt out one or two per MFMA (the scheduling barriers pin that order).  MAIN: a step of the
+    // steady state (step g+1 exists and step g+NST is still to be fetched): no conditions inside.
+    auto step = [&](int g, gemm_frag& cur, gemm_frag& nxt, auto main_tag) __attribute__((always_inline)) {
+        constexpr bool MAIN = decltype(main_tag)::value;
+        frags_landed(cur);
+        if (__builtin_expect(c_t == 0 && g > 0, 0)) {            // first k-step of a tile: the previous tile leaves the accumulators
+            counted = epilogue(c_v - 1);
+            int m0, n0, slab;
+            tile_at(c_v, m0, n0, slab);
+            load_bias(n0);
+        }
+        const bool more = MAIN || g + 1 < total;            // (uniform)
+        const bool dma = MAIN || (more && gi < total);
+        const uint32_t so = (uint32_t)st_c * (STAGE * 4);
+        __builtin_amdgcn_sched_barrier(0);
+        auto body = [&](auto first) __attribute__((always_inline)) {
+        gemm_static_for<0, 32>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            mfma1(cur, ic, first);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (i == 0) {
+                if (more) {
+                    // step g+1 has landed once only what was issued after it is outstanding: NST-2 DMA groups, plus the epilogue's
+                    // operations while the awaited group is older than them (the first NST-1 steps of a tile)
+                    if (!MAIN && g + NST > total) gemm_wait_vm<0>();
+                    else if (__builtin_expect(counted && c_t <= NST - 2, 0)) gemm_wait_vm<(NST - 2) * 4 + EXTRA>();
+                    else gemm_wait_vm<(NST - 2) * 4>();
+                }
+            } else if constexpr (i == 1) {
+                // everyone's pieces of step g+1 are in LDS; everyone has the fragments of step g in registers
+#ifndef GEMM_EXP_NO_BARRIER
+                if (more) __builtin_amdgcn_s_barrier();
+#endif
+            } else if constexpr (i >= 2 && i <= 9) {
+#ifdef GEMM_EXP_NO_READS
+                if (A == nullptr)
+#endif
+                if (more) {
+                    constexpr int p = (i - 2) >> 1, gg = p >> 1, u = (i - 2) & 1;       // piece (k-group, operand), 32-row tile u
+                    if constexpr ((p & 1) == 0) nxt.a[gg][u] = gemm_lds_read128<u * 32 * BKT * 4>(fa[gg] + so);
+                    else nxt.b[gg][u] = gemm_lds_read128<u * 32 * BKT * 4>(fb[gg] + so);
+                }
+            } else if constexpr (i == 12 || i == 16) {
+#ifdef GEMM_EXP_NO_DMA
+                if (A == nullptr)
+#endif
+                if (dma) issue_half((i - 12) >> 2);           // step g+NST into the stage of step g
+            } else if constexpr (i == 20) {
+                if (dma) issue_done();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        };
+        if (__builtin_expect(c_t == 0, 0)) body(std::true_type());
+        else body(std::false_type());
+        if (++st_c == NST) st_c = 0;
+        if (++c_t == T) { c_t = 0; ++c_v; }
+    };
+    {
+        int g = 0;
+        // steady state: two steps per trip (the fragment sets swap roles), while both have a step to fetch
+        for (; g + 1 + NST < total; g += 2) {
+            step(g, F0, F1, std::true_type());
+            step(g + 1, F1, F0, std::true_type());
+        }
+        for (; g < total; g += 2) {
+            step(g, F0, F1, std::false_type());
+            if (g + 1 < total) step(g + 1, F1, F0, std::false_type());
+        }
+    }
+    epilogue(c_v - 1);
+}
+
+static int gemm_1w_grid() {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        else n_cu = 256;
+    }
+    return n_cu & ~7;
+}
+template <int EPI>
+static int gemm_1w_attr() {     // > 64 KB of dynamic LDS needs the attribute, once per device
+    static bool done[64] = {};
+    int dev = 0;
+    SAGA_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !done[dev]) {
+        SAGA_HIP(hipFuncSetAttribute((const void*)gemm_nt_f32_1w_kernel<EPI, GEMM1W_NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     GEMM1W_LDS_BYTES));
+        done[dev] = true;
+    }
+    return 0;
+}
+
 // v_posed[B,Npad] = v_template + feat . Bt^T
 int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed, int B, hipStream_t st) {
     const int tiles_m = (B + BM - 1) / BM, tiles_n = m->Npad / BN;
@@ -311,6 +752,14 @@ int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed
         const int tm = (B + 63) / 64, tn = m->Npad / 64;
         gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD, 1><<<dim3(tm * tn), 256, 0, st>>>(feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template,
                                                                                       nullptr, B, m->Npad, FEAT_K, FEAT_K, tm);
+        SAGA_LAUNCH_CHECK();
+        return 0;
+    }
+    static const int want_1w = getenv("SAGA_GEMM_1W") ? atoi(getenv("SAGA_GEMM_1W")) : 0;        // SAGA_GEMM_1W=1: the one-wave-per-SIMD kernel (experiment)
+    if (want_1w && !want_lepi && n_tiles >= gemm_1w_grid() && n_tiles <= (long)gemm_1w_grid() * GEMM1W_MAX_TILES && FEAT_K / GEMM_BKT >= GEMM1W_NST) {
+        if (int rc = gemm_1w_attr<0>()) return rc;
+        gemm_nt_f32_1w_kernel<0, GEMM1W_NST><<<dim3(gemm_1w_grid()), 256, GEMM1W_LDS_BYTES, st>>>(
+            feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template, B, m->Npad, FEAT_K, FEAT_K, tiles_m, xcd_map, n_tiles, n_tiles);
         SAGA_LAUNCH_CHECK();
         return 0;
     }
@@ -362,6 +811,16 @@ int saga_launch_blend_bwd(const saga_model* m, const float* g_vposed, float* sla
         const int tm = (B + 63) / 64, tn = FEAT_K / 64;
         gemm_nt_f32_kernel<1, GEMM_BKT, GEMM_NST_BWD, 1><<<dim3(tm * tn, 1, splitk), 256, 0, st>>>(g_vposed, m->Npad, m->Bk, m->Npad, slabs, FEAT_K,
                                                                                                  nullptr, nullptr, B, FEAT_K, m->Npad, kchunk, tm);
+        SAGA_LAUNCH_CHECK();
+        return 0;
+    }
+    static const int want_1w = getenv("SAGA_GEMM_1W") ? atoi(getenv("SAGA_GEMM_1W")) : 0;
+    if (want_1w && tiles_m * tiles_n * splitk >= gemm_1w_grid() && tiles_m * tiles_n * splitk <= (long)gemm_1w_grid() * GEMM1W_MAX_TILES &&
+        kchunk * splitk == m->Npad && kchunk / GEMM_BKT >= GEMM1W_NST) {
+        if (int rc = gemm_1w_attr<1>()) return rc;
+        gemm_nt_f32_1w_kernel<1, GEMM1W_NST><<<dim3(gemm_1w_grid()), 256, GEMM1W_LDS_BYTES, st>>>(
+            g_vposed, m->Npad, m->Bk, m->Npad, slabs, FEAT_K, nullptr, B, FEAT_K, m->Npad, kchunk, tiles_m, xcd_map, tiles_m * tiles_n,
+            tiles_m * tiles_n * splitk);
         SAGA_LAUNCH_CHECK();
         return 0;
     }

@@ -8,7 +8,8 @@ OUT=../../build/variants; OBJ=../../build/obj_$NAME
 mkdir -p $OUT $OBJ
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=fast-honor-pragmas $*"
 for f in model pose blend_gemm skin chamfer normals smplx_api grasp_loss rot6d fit_step rows motion_terms; do
-  /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $OBJ/$f.o &
+  X=""; [ $f = blend_gemm ] && X="-mllvm -amdgpu-mfma-vgpr-form=1"      # as the Makefile
+  /opt/rocm/bin/hipcc $FLAGS $X -c $f.hip -o $OBJ/$f.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsaga_$NAME.so $OBJ/*.o
