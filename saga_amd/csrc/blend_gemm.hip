@@ -2,11 +2,20 @@
 //   forward : v_posed[B, Npad]  = v_template + feat[B,512] . Bt[Npad,512]^T      (shape + pose blend shapes, K = 20+486 -> 512)
 //   backward: g_feat[B, 512]    = g_v_posed[B,Npad] . Bk[512,Npad]^T              (split-K slabs, summed by pose_bwd_kernel)
 // Both operands are stored with the contraction index contiguous.  Staging is LDS-DMA (global_load_lds_dwordx4: no
-// staging VGPRs, no ds_write): one wave-instruction moves 8 rows x 128 B into a lane-linear [128 rows][8 x 16 B] image;
-// the bank-conflict swizzle (16-B slot ^= (row>>1)&7) is applied on the per-lane SOURCE address and again on the
-// ds_read_b128 address.  Two LDS stages, tile t+1 in flight while tile t is multiplied, one barrier per k-tile.
+// staging VGPRs, no ds_write): one wave-instruction moves 16 rows x 64 B into a lane-linear [128 rows][4 x 16 B] image;
+// the bank-conflict swizzle (16-B slot ^= (row>>2)&3) is applied on the per-lane SOURCE offset and again on the
+// ds_read_b128 address.  4 (forward) / 5 (split-K backward) LDS stages, one counted vmcnt wait and one barrier per k-tile.
 // v_mfma_f32_32x32x2_f32 is an exact f32 FMA chain (no xf32 on gfx950): lanes 0-31 supply k = 8g+t, lanes 32-63
 // k = 8g+4+t for MFMA t of k-group g -- any k permutation is valid as long as A and B agree.
+//
+// What shapes the k-loop (measured: scripts/ab/mfma_share_ab.hip, scripts/ab/store_pattern_ab.hip, scripts/exp/gemm_trace.py;
+// DESIGN.md section 4): two blocks share a CU, i.e. two waves a SIMD.  Their MFMAs share the matrix pipe perfectly (64 cycles
+// each, 128 per wave and MFMA when both issue) -- but whatever ELSE a wave issues while its partner is inside a burst of MFMAs
+// waits for a gap in that burst: an epilogue of ~400 instructions took 25-30 k cycles, 16 stores alone 55 k in the microbenchmark
+// (700 cycles with the CU to itself).  So the k-loop contains no vector instruction but the MFMAs: scalar LDS-DMA targets (uniform
+// wave id), scalar-base LDS-DMA addresses (inline asm: the builtin takes per-lane 64-bit addresses), fragment reads whose stage and
+// row tile are immediate offsets (k-loop unrolled by the stage count), and the epilogue is one address per 32-row tile + the bias
+// adds + 16 stores.  Forward 1.06 -> 1.03 ms, backward 0.97 -> 0.90 ms at B = 4096, bit-identical.
 // Replaces smplx.lbs.blend_shapes + the posedirs matmul.
 #include <stdlib.h>
 
@@ -47,11 +56,6 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
     else static_assert(N == 0, "unsupported vmcnt");
 }
 
-// Fragment reads as inline asm.  hipcc treats every ds_read after an outstanding LDS-DMA as a possible alias of it and drains vmcnt(0)
-// first -- in a loop that is EVERY k-step (the DMA of the step before is still in flight), so the deep stage ring degenerates to
-// "wait for the youngest tile": the load latency of one tile had to fit into one k-step.  The asm reads are invisible to that rule;
-// the counted vmcnt wait + barrier at the top of the step is what orders them after the DMA that filled their stage, and the
-// lgkmcnt waits below (tied to the destination registers, so the MFMAs cannot move above them) order the MFMAs after the reads.
 template <int I, int N, class F>
 __device__ __forceinline__ void gemm_static_for(F&& f) {       // f(integral_constant<int, I>) for I..N-1: every index a constant
     if constexpr (I < N) {                                      // (a plain unrolled loop left the accumulator array in scratch)
@@ -59,6 +63,21 @@ __device__ __forceinline__ void gemm_static_for(F&& f) {       // f(integral_con
         gemm_static_for<I + 1, N>(f);
     }
 }
+// One LDS-DMA wave-instruction (64 lanes x 16 B -> 1 KiB of LDS at lds_addr, lane-linear) in the scalar-base form: global address =
+// 64-bit scalar base + the lane's 32-bit byte offset.  hipcc's builtin always takes a 64-bit per-lane address, i.e. one 64-bit
+// vector add per transfer -- vector instructions are what this kernel cannot afford inside its k-loop (see below).  M0 (the LDS
+// target) is set here; the kernel has no other user of it.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void gemm_lds_dma16(uint32_t voff, const char* sbase, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+// Fragment reads as inline asm.  hipcc treats every ds_read after an outstanding LDS-DMA as a possible alias of it and drains vmcnt(0)
+// first -- in a loop that is EVERY k-step (the DMA of the step before is still in flight), so the deep stage ring degenerates to
+// "wait for the youngest tile": the load latency of one tile had to fit into one k-step.  The asm reads are invisible to that rule;
+// the counted vmcnt wait + barrier at the top of the step is what orders them after the DMA that filled their stage, and the
+// lgkmcnt waits below (tied to the destination registers, so the MFMAs cannot move above them) order the MFMAs after the reads.
 typedef float gemm_f4 __attribute__((ext_vector_type(4)));
 template <int OFF>
 __device__ __forceinline__ gemm_f4 gemm_lds_read128(uint32_t addr) {
@@ -97,7 +116,7 @@ extern "C" int saga_debug_gemm_trace(unsigned long long* host, size_t n) {
 // EPI 1: C[z][row][col] = acc                    (slab z = blockIdx.z, slab stride M*ldc)
 // EPI 2: C[row][col] = leaky_relu(acc + bias[col], 0.2)                    (VPoser decoder layers, fit_step.hip)
 // EPI 3: C[row][col] = acc * (aux[row][col] > 0 ? 1 : 0.2)                 (their backward; aux = the layer's output)
-// BKT  : k-depth of one LDS tile (16 or 32); NST: LDS stages (NST-1 tiles in flight beside the one being multiplied)
+// BKT  : k-depth of one LDS tile (16); NST: LDS stages (NST-1 tiles in flight beside the one being multiplied)
 // WT   : 32x32 MFMA tiles per wave and dimension: 2 -> 128x128 block tile (the blend contraction), 1 -> 64x64 (the small
 //        decoder layers, which need 4x the blocks to fill 256 CUs)
 // TRS  : accumulate the TRANSPOSED 32x32 tiles (MFMA operands swapped; same products, same order, same bits): a lane then
@@ -190,10 +209,12 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
         constexpr int STG = decltype(stg)::value;
         float* sa = smem + STG * (2 * TILE_FLOATS) + wave * (PPW * 256);
         float* sb = sa + TILE_FLOATS;
+        const char* ak = a_base + koff;
+        const char* bk = b_base + koff;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_base + koff + a_off[j]), (lds_ptr_t)(sa + j * 256), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b_base + koff + b_off[j]), (lds_ptr_t)(sb + j * 256), 16, 0, 0);
+            gemm_lds_dma16(a_off[j], ak, (uint32_t)(uintptr_t)(lds_ptr_t)(sa + j * 256));
+            gemm_lds_dma16(b_off[j], bk, (uint32_t)(uintptr_t)(lds_ptr_t)(sb + j * 256));
         }
     };
 
@@ -417,321 +438,6 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     }       // tiles of this block
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// The blend contraction as ONE wave per SIMD (one 4-wave block per CU, persistent).  Measured on MI355X (scripts/ab/
-// mfma_share_ab.hip, store_pattern_ab.hip, scripts/exp/gemm_trace.py): two waves share a SIMD's matrix pipe perfectly as long as
-// both only issue MFMAs, but whatever else one of them has to issue -- the 16 stores of an epilogue, the address arithmetic of
-// its LDS-DMA -- crawls while its partner is inside an MFMA burst (an epilogue of 16 stores took 25-55 k cycles against 700
-// alone), and the partner does not make up for it: two blocks per CU lose 15-19 % of the matrix pipe, one block per CU with
-// nothing but MFMAs and stores runs at 99 %.  So this kernel gives each SIMD a single wave that hides everything in the shadow of
-// its own MFMAs (an MFMA occupies the pipe for 64 cycles, the wave is free to issue ~10 other instructions meanwhile):
-//   * the fragments of k-step s+1 are read from LDS into a second register set between the two MFMA groups of step s;
-//   * the LDS-DMA of step s+NST is issued there too, into the stage the block has just finished reading: NST-1 steps of latency
-//     cover; the stream of k-steps runs ACROSS tiles, so a tile's first operands are in flight during the previous tile's last steps;
-//   * the epilogue of a tile (accumulators + bias -> 16 stores per wave) runs at the top of the next tile's first step; the bias
-//     quads of a tile are fetched a whole tile ahead by asm loads the compiler does not wait for; vmcnt is counted by hand
-//     (in-order: DMA groups of 4, an epilogue's 16 stores + 8 bias loads).
-// Same products in the same order as gemm_nt_f32_kernel: bit-identical results (tests/test_gpu_smplx.py).
-#ifndef GEMM1W_NST
-#define GEMM1W_NST 6
-#endif
-#define GEMM1W_MAX_TILES 1024      // tiles per block the LDS tile table holds (12 KB)
-#define GEMM1W_LDS_BYTES (GEMM1W_NST * 2 * 128 * 16 * 4 + GEMM1W_MAX_TILES * 12)
-struct gemm_frag { gemm_f4 a[2][2], b[2][2]; };       // [k-group][32-row tile] of the wave's 64 x 64 tile
-template <int N>
-__device__ __forceinline__ void gemm_wait_vm() {
-    static_assert(N >= 0 && N <= 63, "vmcnt");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-template <int EPI, int NST>
-__global__ __launch_bounds__(256, 1) void gemm_nt_f32_1w_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bt,
-                                                                int ldb, float* __restrict__ C, int ldc,
-                                                                const float* __restrict__ bias, int M, int N, int K, int kchunk,
-                                                                int tiles_m, int xcd_map, int per, int n_virtual) {
-    constexpr int BKT = 16, TILE_FLOATS = 128 * BKT, STAGE = 2 * TILE_FLOATS;
-    constexpr int EXTRA = EPI == 0 ? 24 : 16;       // vector-memory operations an epilogue puts into the in-order stream
-    extern __shared__ __attribute__((aligned(1024))) float smem1w[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
-    const int T = kchunk / BKT;
-    if ((int)blockIdx.x >= n_virtual) return;
-    const int n_my = (n_virtual - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
-    const int total = n_my * T;
-
-    // virtual tile id -> (m0, n0, slab): the ownership maps of gemm_nt_f32_kernel (gridDim.x a multiple of 8: v & 7 = this block's XCD)
-    auto coords = [&](int v, int& m0, int& n0, int& slab) __attribute__((always_inline)) {
-        const int z = v / per, bx = v - z * per;
-        int tile_m = bx % tiles_m, tile_n = bx / tiles_m;
-        slab = z;
-        if (xcd_map == 2) {
-            const int x = v & 7, i = v >> 3;
-            slab = x + 8 * (i / per);
-            const int t = i % per, tiles_n = per / tiles_m;
-            tile_n = t % tiles_n;
-            tile_m = t / tiles_n;
-        } else if (xcd_map) {
-            const int x = bx & 7, i = bx >> 3;
-            const int mq = tiles_m >> 2, nh = (per / tiles_m) >> 1;
-            tile_m = (x & 3) * mq + i % mq;
-            tile_n = (x >> 2) * nh + i / mq;
-        }
-        m0 = tile_m * 128;
-        n0 = tile_n * 128;
-    };
-
-    // the block's tiles (m0, n0, slab), worked out once: the ownership maps divide by run-time numbers, and a wave alone on its SIMD
-    // has no partner to hide ~20 scalar instructions per division behind (they sat between two MFMAs of the steady-state loop)
-    int* tile_tab = reinterpret_cast<int*>(smem1w + NST * STAGE);
-    for (int i = tid; i < n_my; i += 256) {
-        int m0, n0, slab;
-        coords((int)blockIdx.x + i * (int)gridDim.x, m0, n0, slab);
-        tile_tab[3 * i] = m0; tile_tab[3 * i + 1] = n0; tile_tab[3 * i + 2] = slab;
-    }
-    __syncthreads();
-    auto tile_at = [&](int i, int& m0, int& n0, int& slab) __attribute__((always_inline)) {
-        m0 = __builtin_amdgcn_readfirstlane(tile_tab[3 * i]);
-        n0 = __builtin_amdgcn_readfirstlane(tile_tab[3 * i + 1]);
-        slab = __builtin_amdgcn_readfirstlane(tile_tab[3 * i + 2]);
-    };
-
-    // ---- issue side: LDS-DMA of global k-step gi (tile number i_v of this block, k-step i_t of it) into stage st_i = gi % NST
-    const float* a_src[2];
-    const float* b_src[2];
-    int i_v = 0, i_t = 0, gi = 0, st_i = 0;
-    auto issue_tile = [&](int v) __attribute__((always_inline)) {
-        int m0, n0, slab;
-        tile_at(v, m0, n0, slab);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = (wave * 2 + j) * 16 + (lane >> 2);
-            const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-            a_src[j] = A + (size_t)min(m0 + row, M - 1) * lda + (size_t)slab * kchunk + chunk * 4;
-            b_src[j] = Bt + (size_t)min(n0 + row, N - 1) * ldb + (size_t)slab * kchunk + chunk * 4;
-        }
-    };
-    // one k-step's LDS-DMA in two halves (j = 0, 1: the wave's two 1-KiB pieces of each operand tile), then the bookkeeping
-    auto issue_half = [&](int j) __attribute__((always_inline)) {
-        float* sa = smem1w + st_i * STAGE + wave * 512;
-        float* sb = sa + TILE_FLOATS;
-        const int koff = i_t * BKT;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[j] + koff), (lds_ptr_t)(sa + j * 256), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b_src[j] + koff), (lds_ptr_t)(sb + j * 256), 16, 0, 0);
-    };
-    auto issue_done = [&]() __attribute__((always_inline)) {
-        ++gi;
-        if (++st_i == NST) st_i = 0;
-        if (__builtin_expect(++i_t == T, 0)) {
-            i_t = 0;
-            ++i_v;
-            if (gi < total) issue_tile(i_v);
-        }
-    };
-    auto issue = [&]() __attribute__((always_inline)) { issue_half(0); issue_half(1); issue_done(); };
-
-    // ---- consume side
-    const int fsw = (l31 >> 2) & 3;
-    uint32_t fa[2], fb[2];          // LDS byte addresses of the wave's fragments in stage 0, per k-group
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int koff = ((2 * g + half) ^ fsw) * 4;
-        fa[g] = (uint32_t)(uintptr_t)(lds_ptr_t)(smem1w + (wm * 64 + l31) * BKT + koff);
-        fb[g] = (uint32_t)(uintptr_t)(lds_ptr_t)(smem1w + TILE_FLOATS + (wn * 64 + l31) * BKT + koff);
-    }
-    // fragment reads in four pieces (interleaved with the MFMAs below): piece p = (k-group p >> 1, operand p & 1)
-    auto read_piece = [&](gemm_frag& f, uint32_t so, int p) __attribute__((always_inline)) {
-        const int g = p >> 1;
-        if ((p & 1) == 0) {
-            f.a[g][0] = gemm_lds_read128<0>(fa[g] + so);
-            f.a[g][1] = gemm_lds_read128<32 * BKT * 4>(fa[g] + so);
-        } else {
-            f.b[g][0] = gemm_lds_read128<0>(fb[g] + so);
-            f.b[g][1] = gemm_lds_read128<32 * BKT * 4>(fb[g] + so);
-        }
-    };
-    auto read_frags = [&](gemm_frag& f, int stage) __attribute__((always_inline)) {
-        const uint32_t so = (uint32_t)stage * (STAGE * 4);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) read_piece(f, so, p);
-    };
-    auto frags_landed = [&](gemm_frag& f) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.a[1][0]), "+v"(f.a[1][1]),
-                       "+v"(f.b[1][0]), "+v"(f.b[1][1])::"memory");
-    };
-    gemm_f4 bq[2][4];               // bias quads of the tile being multiplied (EPI 0)
-    auto load_bias = [&](int n0) __attribute__((always_inline)) {
-        if (EPI != 0) return;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float* p = bias + n0 + wn * 64 + nt * 32 + 8 * q + 4 * half;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[nt][q]) : "v"(p) : "memory");
-            }
-    };
-    f32x16 acc[2][2];
-    // accumulators (+ bias) -> C; returns whether it issued exactly its 16 stores per lane-active wave (whole tile)
-    auto epilogue = [&](int v) __attribute__((always_inline)) -> bool {
-        int m0, n0, slab;
-        tile_at(v, m0, n0, slab);
-        float* Cz = C;
-        if (EPI == 1) Cz += (size_t)slab * M * ldc;
-        const bool full = m0 + 128 <= M;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int row = m0 + wm * 64 + mt * 32 + l31;
-            if (!full && row >= M) continue;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int col = n0 + wn * 64 + nt * 32 + 8 * q + 4 * half;
-                    float4 o = make_float4(acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]);
-                    if (EPI == 0) { o.x += bq[nt][q].x; o.y += bq[nt][q].y; o.z += bq[nt][q].z; o.w += bq[nt][q].w; }
-#ifdef GEMM_EXP_NO_STORE
-                    if (o.x == 123.456f)
-#endif
-                    *reinterpret_cast<float4*>(Cz + (size_t)row * ldc + col) = o;
-                }
-        }
-#ifdef GEMM_EXP_NO_STORE
-        return false;
-#endif
-        return full;
-    };
-
-    // ---- prologue: bias of the first tile, NST k-steps in flight, fragments of step 0
-    int c_v = 0, c_t = 0, st_c = 1;         // tile number / k-step being multiplied; stage of the NEXT step
-    bool counted = false;                   // the current tile began with a whole epilogue: EXTRA operations sit in the vmcnt stream
-    {
-        int m0, n0, slab;
-        tile_at(c_v, m0, n0, slab);
-        load_bias(n0);
-    }
-    issue_tile(i_v);
-    for (int s = 0; s < NST && s < total; ++s) issue();
-    if (total > NST - 1) gemm_wait_vm<(NST - 1) * 4>(); else gemm_wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    gemm_frag F0, F1;
-    read_frags(F0, 0);
-#ifdef GEMM_EXP_NO_READS
-    read_frags(F1, 0);
-#endif
-
-    // MFMA i of a k-step (i = 0..31): k-group i >> 4, k-value (i >> 2) & 3, accumulator i & 3 -- round-robin over the four accumulators
-    // (a wave alone on its SIMD must not issue an MFMA that depends on the one before it); every accumulator still sums its k in
-    // ascending order: the bits of gemm_nt_f32_kernel
-    // `first`: the first k-step of a tile -- its first four MFMAs take the constant 0 as their C operand, so the accumulators are never
-    // written by anything but an MFMA (they stay in the AGPR file, which nothing else in the loop touches: see the Makefile note)
-    auto mfma1 = [&](const gemm_frag& f, auto ic, auto first) __attribute__((always_inline)) {
-        constexpr int i = decltype(ic)::value;
-        constexpr int g = i >> 4, kk = (i >> 2) & 3, mt = (i >> 1) & 1, nt = i & 1;
-        if constexpr (decltype(first)::value && i < 4) {
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b[g][nt][kk], f.a[g][mt][kk], zero, 0, 0, 0);
-        } else {
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b[g][nt][kk], f.a[g][mt][kk], acc[mt][nt], 0, 0, 0);
-        }
-    };
-    // One k-step: global step g multiplies the fragments in `cur` and fetches those of step g + 1 into `nxt`.  An MFMA occupies the
-    // pipe for 64 cycles and the wave issues in order, so whatever stands between two MFMAs must fit into those 64 cycles: the ~45
-    // other instructions of a step are dealt out one or two per MFMA (the scheduling barriers pin that order).  MAIN: a step of the
-    // steady state (step g+1 exists and step g+NST is still to be fetched): no conditions inside.
-    auto step = [&](int g, gemm_frag& cur, gemm_frag& nxt, auto main_tag) __attribute__((always_inline)) {
-        constexpr bool MAIN = decltype(main_tag)::value;
-        frags_landed(cur);
-        if (__builtin_expect(c_t == 0 && g > 0, 0)) {            // first k-step of a tile: the previous tile leaves the accumulators
-            counted = epilogue(c_v - 1);
-            int m0, n0, slab;
-            tile_at(c_v, m0, n0, slab);
-            load_bias(n0);
-        }
-        const bool more = MAIN || g + 1 < total;            // (uniform)
-        const bool dma = MAIN || (more && gi < total);
-        const uint32_t so = (uint32_t)st_c * (STAGE * 4);
-        __builtin_amdgcn_sched_barrier(0);
-        auto body = [&](auto first) __attribute__((always_inline)) {
-        gemm_static_for<0, 32>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            mfma1(cur, ic, first);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (i == 0) {
-                if (more) {
-                    // step g+1 has landed once only what was issued after it is outstanding: NST-2 DMA groups, plus the epilogue's
-                    // operations while the awaited group is older than them (the first NST-1 steps of a tile)
-                    if (!MAIN && g + NST > total) gemm_wait_vm<0>();
-                    else if (__builtin_expect(counted && c_t <= NST - 2, 0)) gemm_wait_vm<(NST - 2) * 4 + EXTRA>();
-                    else gemm_wait_vm<(NST - 2) * 4>();
-                }
-            } else if constexpr (i == 1) {
-                // everyone's pieces of step g+1 are in LDS; everyone has the fragments of step g in registers
-#ifndef GEMM_EXP_NO_BARRIER
-                if (more) __builtin_amdgcn_s_barrier();
-#endif
-            } else if constexpr (i >= 2 && i <= 9) {
-#ifdef GEMM_EXP_NO_READS
-                if (A == nullptr)
-#endif
-                if (more) {
-                    constexpr int p = (i - 2) >> 1, gg = p >> 1, u = (i - 2) & 1;       // piece (k-group, operand), 32-row tile u
-                    if constexpr ((p & 1) == 0) nxt.a[gg][u] = gemm_lds_read128<u * 32 * BKT * 4>(fa[gg] + so);
-                    else nxt.b[gg][u] = gemm_lds_read128<u * 32 * BKT * 4>(fb[gg] + so);
-                }
-            } else if constexpr (i == 12 || i == 16) {
-#ifdef GEMM_EXP_NO_DMA
-                if (A == nullptr)
-#endif
-                if (dma) issue_half((i - 12) >> 2);           // step g+NST into the stage of step g
-            } else if constexpr (i == 20) {
-                if (dma) issue_done();
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        };
-        if (__builtin_expect(c_t == 0, 0)) body(std::true_type());
-        else body(std::false_type());
-        if (++st_c == NST) st_c = 0;
-        if (++c_t == T) { c_t = 0; ++c_v; }
-    };
-    {
-        int g = 0;
-        // steady state: two steps per trip (the fragment sets swap roles), while both have a step to fetch
-        for (; g + 1 + NST < total; g += 2) {
-            step(g, F0, F1, std::true_type());
-            step(g + 1, F1, F0, std::true_type());
-        }
-        for (; g < total; g += 2) {
-            step(g, F0, F1, std::false_type());
-            if (g + 1 < total) step(g + 1, F1, F0, std::false_type());
-        }
-    }
-    epilogue(c_v - 1);
-}
-
-static int gemm_1w_grid() {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        else n_cu = 256;
-    }
-    return n_cu & ~7;
-}
-template <int EPI>
-static int gemm_1w_attr() {     // > 64 KB of dynamic LDS needs the attribute, once per device
-    static bool done[64] = {};
-    int dev = 0;
-    SAGA_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !done[dev]) {
-        SAGA_HIP(hipFuncSetAttribute((const void*)gemm_nt_f32_1w_kernel<EPI, GEMM1W_NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     GEMM1W_LDS_BYTES));
-        done[dev] = true;
-    }
-    return 0;
-}
-
 // v_posed[B,Npad] = v_template + feat . Bt^T
 int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed, int B, hipStream_t st) {
     const int tiles_m = (B + BM - 1) / BM, tiles_n = m->Npad / BN;
@@ -752,14 +458,6 @@ int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed
         const int tm = (B + 63) / 64, tn = m->Npad / 64;
         gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD, 1><<<dim3(tm * tn), 256, 0, st>>>(feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template,
                                                                                       nullptr, B, m->Npad, FEAT_K, FEAT_K, tm);
-        SAGA_LAUNCH_CHECK();
-        return 0;
-    }
-    static const int want_1w = getenv("SAGA_GEMM_1W") ? atoi(getenv("SAGA_GEMM_1W")) : 0;        // SAGA_GEMM_1W=1: the one-wave-per-SIMD kernel (experiment)
-    if (want_1w && !want_lepi && n_tiles >= gemm_1w_grid() && n_tiles <= (long)gemm_1w_grid() * GEMM1W_MAX_TILES && FEAT_K / GEMM_BKT >= GEMM1W_NST) {
-        if (int rc = gemm_1w_attr<0>()) return rc;
-        gemm_nt_f32_1w_kernel<0, GEMM1W_NST><<<dim3(gemm_1w_grid()), 256, GEMM1W_LDS_BYTES, st>>>(
-            feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template, B, m->Npad, FEAT_K, FEAT_K, tiles_m, xcd_map, n_tiles, n_tiles);
         SAGA_LAUNCH_CHECK();
         return 0;
     }
@@ -811,16 +509,6 @@ int saga_launch_blend_bwd(const saga_model* m, const float* g_vposed, float* sla
         const int tm = (B + 63) / 64, tn = FEAT_K / 64;
         gemm_nt_f32_kernel<1, GEMM_BKT, GEMM_NST_BWD, 1><<<dim3(tm * tn, 1, splitk), 256, 0, st>>>(g_vposed, m->Npad, m->Bk, m->Npad, slabs, FEAT_K,
                                                                                                  nullptr, nullptr, B, FEAT_K, m->Npad, kchunk, tm);
-        SAGA_LAUNCH_CHECK();
-        return 0;
-    }
-    static const int want_1w = getenv("SAGA_GEMM_1W") ? atoi(getenv("SAGA_GEMM_1W")) : 0;
-    if (want_1w && tiles_m * tiles_n * splitk >= gemm_1w_grid() && tiles_m * tiles_n * splitk <= (long)gemm_1w_grid() * GEMM1W_MAX_TILES &&
-        kchunk * splitk == m->Npad && kchunk / GEMM_BKT >= GEMM1W_NST) {
-        if (int rc = gemm_1w_attr<1>()) return rc;
-        gemm_nt_f32_1w_kernel<1, GEMM1W_NST><<<dim3(gemm_1w_grid()), 256, GEMM1W_LDS_BYTES, st>>>(
-            g_vposed, m->Npad, m->Bk, m->Npad, slabs, FEAT_K, nullptr, B, FEAT_K, m->Npad, kchunk, tiles_m, xcd_map, tiles_m * tiles_n,
-            tiles_m * tiles_n * splitk);
         SAGA_LAUNCH_CHECK();
         return 0;
     }

@@ -1,5 +1,5 @@
 """Hashes of the SMPL-X forward vertices and parameter gradients at several batch sizes: run under two library settings (e.g.
-SAGA_GEMM_1W=0 / 1) and compare the lines -- the blend GEMM variants must agree bit for bit."""
+SAGA_GEMM_SMALL=0 / 1, or two builds through SAGA_HIP_LIB) and compare the lines -- blend GEMM variants must agree bit for bit."""
 import os, sys, tempfile, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
