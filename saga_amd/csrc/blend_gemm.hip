@@ -35,7 +35,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GEMM_NST_FWD
 #define GEMM_NST_FWD 4      // LDS stages, forward
 #endif
+#ifndef GEMM_NST_BWD
 #define GEMM_NST_BWD 5      // LDS stages, backward (split-K)
+#endif
 #define GEMM_SMALL_TILES 256 // launches of at most this many 128 x 128 tiles (less than one per CU) run 64 x 64 tiles instead
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -466,10 +468,12 @@ int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed
         gemm_nt_f32_kernel<0, GEMM_BKT, GEMM_NST_FWD, 2, true, true><<<grid, 256, 0, st>>>(feat, FEAT_K, m->Bt, FEAT_K, v_posed, m->Npad, m->v_template,
                                                                                             nullptr, B, m->Npad, FEAT_K, FEAT_K, tiles_m, xcd_map, n_tiles);
     } else {
-        // persistent launch: two blocks per CU (what the 64 KB of LDS stages allow) walk the tiles -- no block turnover between
-        // tiles: 1.068 -> 1.059 ms at B = 4096 (SAGA_GEMM_PERSIST=0: one block per tile; =n: n blocks).  What the per-tile
-        // overheads are worth in all (measured with -DGEMM_EXP_NO_STORE, wrong results): no epilogue stores at all 1.027 ms.
-        static const int persist_env = getenv("SAGA_GEMM_PERSIST") ? atoi(getenv("SAGA_GEMM_PERSIST")) : -1;
+        // One block per tile, handed out by the hardware.  (A persistent launch -- SAGA_GEMM_PERSIST=-1: two blocks per CU, =n: n blocks,
+        // each walking an equal share of the tiles -- was the default while the k-loop still carried vector arithmetic: 1.068 -> 1.059
+        // ms.  With the lean loop the time stamps show the two blocks of a CU running very unequally -- the wave that came first wins
+        // the SIMD's arbitration and takes a tile in ~100 k cycles, its partner fills the gaps and needs ~260 k -- so equal shares
+        // leave the second block alone on its CU for the last third of the launch: 1.027 ms against 0.993 for this form.)
+        static const int persist_env = getenv("SAGA_GEMM_PERSIST") ? atoi(getenv("SAGA_GEMM_PERSIST")) : 0;
         int persist = persist_env;
         if (persist < 0) {
             static int n_cu = 0;
