@@ -313,7 +313,7 @@ def main():
         if not (args.sparse_backward or args.loss_vertices_only or args.autograd or args.local_weights or args.mesh_faces):
             out['config']['variants_reported_separately'] = (
                 'bench.py --sparse-backward (saga_fit_step_sparse: same full-mesh forward, backward over the loss vertices only; '
-                'profiles/round2_e_lines/bench_sparse_backward.json: 2.81 ms per iteration), --loss-vertices-only, --mesh-faces / --local-weights '
+                'profiles/round2_f_lines/bench_sparse_backward.json: 2.78 ms per iteration), --loss-vertices-only, --mesh-faces / --local-weights '
                 '(mesh-like synthetic model: 4.02 ms); never the headline')
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only (host cores are shared by the ranks)
             # the oracle at B=1 (the reference's own semantics: one candidate at a time) AND at B=64 (batched, to be
