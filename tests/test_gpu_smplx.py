@@ -96,6 +96,31 @@ def test_backward_full_mesh(body_model_dir):
         assert e < GRAD_TOL, (k, e)
 
 
+def test_ragged_batch_on_the_large_tile_path_equals_small_batches_bit_for_bit(body_model_dir):
+    """B = 520 is four whole 128-row tiles and one of 8 rows, on the 128 x 128 launches of the blend contraction in both
+    directions (forward 5 x 246 tiles, backward 5 x 4 x 16); a batch of 5 runs the 64 x 64 launches.  Same products in the
+    same order: a candidate's vertices and parameter gradients must not depend on which of the two it went through, nor
+    on its position in a partly filled tile."""
+    B = 520
+    sel = [0, 127, 128, 511, 512, 519]
+    inp = random_body_inputs(B, seed=77)
+    w = torch.randn(B, 10475, 3, generator=torch.Generator().manual_seed(5))
+
+    def run(idx):
+        hip = make_hip_model(body_model_dir, len(idx))
+        x = to_cuda({k: v[idx] for k, v in inp.items()}, requires_grad=True)
+        out = hip(return_verts=True, **x)
+        (out.vertices * w[idx].cuda()).sum().backward()
+        return out.vertices.detach(), {k: v.grad for k, v in x.items()}
+
+    v_big, g_big = run(list(range(B)))
+    v_small, g_small = run(sel)
+    assert torch.equal(v_big[sel], v_small)
+    for k in g_small:
+        assert torch.equal(g_big[k][sel], g_small[k]), k
+    assert torch.isfinite(v_big).all()
+
+
 @pytest.mark.parametrize('variant', [
     dict(n_verts=2100, n_faces=4100, dense_weights=True),   # dense table over 3 vertex ranges: the MFMA dA reduction
     dict(n_verts=3000, n_faces=5900, weights_nnz=6),        # 6 non-zeros per vertex: generic sparse path, one block per candidate
