@@ -23,6 +23,9 @@ __global__ __launch_bounds__(256) void k(float* C, int ldc, int tiles_m, int n_t
                 for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
         const int m0 = (bx % tiles_m) * 128, n0 = (bx / tiles_m) * 128;
         long long t0 = clock64();
+#ifdef EPI_PRIO
+        __builtin_amdgcn_s_setprio(EPI_PRIO);
+#endif
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -41,6 +44,9 @@ __global__ __launch_bounds__(256) void k(float* C, int ldc, int tiles_m, int n_t
                     else off = (size_t)(m0 + wm * 64 + mt * 32 + q * 8 + nt * 4 + (lane >> 4)) * ldc + n0 + wn * 64 + (lane & 15) * 4;
                     *reinterpret_cast<float4*>(C + off) = make_float4(acc[mt * 2 + nt][4 * q], acc[mt * 2 + nt][4 * q + 1], acc[mt * 2 + nt][4 * q + 2], acc[mt * 2 + nt][4 * q + 3]);
                 }
+#ifdef EPI_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         in_epi += clock64() - t0;
     }
     if (threadIdx.x == 0) { cyc[2 * blockIdx.x] = in_epi; cyc[2 * blockIdx.x + 1] = clock64() - t_begin; }
