@@ -2,6 +2,7 @@
 -DGEMM_EXP_TRACE; run with SAGA_HIP_LIB=build/variants/libsaga_tr.so): which blocks share a CU, and whether their prologues /
 epilogues coincide."""
 import os, sys, tempfile, ctypes, collections
+os.environ.setdefault('SAGA_GEMM_PERSIST', '-1')     # the stamps are taken in the persistent form of the launch (two blocks per CU walking the tiles)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from saga_amd import _lib, smplx
