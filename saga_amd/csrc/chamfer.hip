@@ -62,7 +62,8 @@ __global__ __launch_bounds__(NTH) void nn_scan_kernel(const float* __restrict__ 
 // clouds (BASELINE config 5: 100,000 points) stream through LDS 2,048 points at a time.
 // MF: approximate pass on the matrix cores (nnf_scan_mfma) instead of the vector units (nnf_scan); same results.
 template <int NQ, int NTH, bool MF>
-__global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 1) void nn_fast_kernel(const float* __restrict__ q, const float* __restrict__ db,
+__global__ __launch_bounds__(NTH, NTH == 256 ? (MF ? 3 : 2) : 1) void nn_fast_kernel(     // (the vector-unit pass is the cross-check path: two blocks per CU, no spills)
+const float* __restrict__ q, const float* __restrict__ db,
                                                       float* __restrict__ dist, int32_t* __restrict__ idx, int Pq, int Pd) {
     __shared__ __attribute__((aligned(16))) float sdb[NNF_TILE_FLOATS(NN_TILE)];
     __shared__ float sred[6 * (NTH / 64)];
@@ -88,8 +89,15 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 1) void nn_fast_kernel(const 
 #pragma unroll
         for (int i = 0; i < NQ; ++i) { qx[i] = ox[i] - f.cx; qy[i] = oy[i] - f.cy; qz[i] = oz[i] - f.cz; }
         __syncthreads();
-        if (MF) nnf_scan_mfma<NQ>(sdb, cnt_pad / NNF_CH, f, qx, qy, qz, m1, m2, m3, c1, c2);
-        else nnf_scan<NQ>(sdb, cnt_pad / NNF_CH, qx, qy, qz, m1, m2, m3, c1, c2);
+        if (MF) {
+            nnf_scan_mfma<NQ>(sdb, cnt_pad / NNF_CH, f, qx, qy, qz, m1, m2, m3, c1, c2);
+            // the framed queries are formed again (same subtraction, same bits) instead of staying live across the matrix-core pass
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                asm volatile("" : "+v"(ox[i]), "+v"(oy[i]), "+v"(oz[i]));
+                qx[i] = ox[i] - f.cx; qy[i] = oy[i] - f.cy; qz[i] = oz[i] - f.cz;
+            }
+        } else nnf_scan<NQ>(sdb, cnt_pad / NNF_CH, qx, qy, qz, m1, m2, m3, c1, c2);
         nnf_resolve<NQ, MF>(sdb, cnt_pad / NNF_CH, f, t0, qx, qy, qz, ox, oy, oz, m1, m2, m3, c1, c2, best, bi);
     }
 #pragma unroll

@@ -29,6 +29,7 @@ int saga_smplx_fwd_sel(const saga_model_t* m, const saga_model_t* sub, const flo
                        float* sel_rows, int B, void* stream, float* sel_verts = nullptr);
 int saga_launch_hand_ring(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* verts, float* uniq_rows,
                           float* hand_normals, int B, void* stream);
+int saga_grasp_loss_fast_ok(const saga_grasp_tables_t* tb, int O);
 int saga_grasp_loss_fwd_pre(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* obj, const float* obj_normals,
                             const float* markers_target, const float* c_markers, const float* c_object, float* terms,
                             float* markers_rec, float* hand_rec, float* hand_normals, const float* uniq_rows, float* h2o_marker,
@@ -574,7 +575,7 @@ static int fit_step_impl(const saga_model_t* m, const saga_model_t* mb, const sa
     // Only for meshes whose faces join far-apart vertices (m->scattered_faces: the SURVEY synthetic model): on a mesh-like face
     // list the corner reads hit L2 and hide under the other blocks' scans -- measured, B = 4096: ring kernel 0.09 + loss 0.86 ms
     // against 0.92 ms for the loss kernel alone there; 0.16 + 0.87 against 1.10 on random faces (SAGA_FIT_PRE=1 forces the ring path).
-    if (!gated_off && O <= 2048 && m->F > 0 && getenv("SAGA_FIT_NO_PRE") == nullptr &&
+    if (!gated_off && saga_grasp_loss_fast_ok(tb, O) && m->F > 0 && getenv("SAGA_FIT_NO_PRE") == nullptr &&
         (m->scattered_faces || getenv("SAGA_FIT_PRE") != nullptr)) {
         rc = saga_launch_hand_ring(m, tb, w.verts, w.uniq_rows, w.hand_nrm, B, stream);
         if (rc != 0 && rc != 1) return rc;

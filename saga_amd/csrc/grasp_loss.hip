@@ -33,6 +33,25 @@ void saga_prof_end(void* scope);
 
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 
+// Sum over the wave, valid in lane 0: the additions of the __shfl_down tree (offsets 32, 16, .., 1) in the same order, so lane 0 holds
+// the same bits -- but with the lane exchanges as v_permlane32_swap / ds_swizzle, whose patterns are immediates: __shfl_down keeps
+// six per-lane ds_bpermute addresses live from the first reduction of a kernel to its last (they were spilled to scratch).
+__device__ __forceinline__ float gl_wave_sum_lane0(float v) {
+    {
+        const unsigned u = (unsigned)__float_as_int(v);
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // [1]: lanes 0..31 hold lanes 32..63
+        v += __int_as_float((int)sw[1]);
+    }
+#define GL_SWZ_XOR(o) __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), ((o) << 10) | 0x1f))
+    v += GL_SWZ_XOR(16);
+    v += GL_SWZ_XOR(8);
+    v += GL_SWZ_XOR(4);
+    v += GL_SWZ_XOR(2);
+    v += GL_SWZ_XOR(1);
+#undef GL_SWZ_XOR
+    return v;
+}
+
 __global__ __launch_bounds__(GL_THREADS) void grasp_loss_fwd_kernel(
     saga_grasp_tables_t tb, const float* __restrict__ verts, const int32_t* __restrict__ vf_ptr,
     const int32_t* __restrict__ vf_tri, const float* __restrict__ obj,
@@ -227,6 +246,13 @@ extern "C" int saga_debug_read_phases(unsigned long long* out) {
 // PRE (saga_fit_step): the vertices the loss reads come as compact rows uniq_rows [B, n_unique, 3] (markers / hand / feet through
 // the tables' *_slot arrays) and hand_normals is an INPUT -- both written by the whole-candidate skinning kernel (skin.hip,
 // skin_fwd_cand_kernel); this kernel then touches neither the mesh nor its faces.
+__host__ __device__ constexpr int glf_hand_off(int H) {       // float offset of the framed hand tile inside the arena
+    return (NNF_TILE_FLOATS(GL_TILE) + NNF_TILE_FLOATS(GL_MAX_HAND) - NNF_TILE_FLOATS((H + 31) & ~31)) & ~3;
+}
+__host__ __device__ constexpr bool glf_hand_fits(int H) {     // A-operand image of the hand tiles + normals in front of the hand tile
+    return (((H + 31) & ~31) >> 5) * 256 + ((H * 3 + 3) & ~3) <= glf_hand_off(H);
+}
+static_assert(glf_hand_fits(778) && glf_hand_fits(800), "SMPL-X's right hand must take the fast kernel");
 template <bool PRE>
 __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     saga_grasp_tables_t tb, const float* __restrict__ verts, const int32_t* __restrict__ vf_ptr,
@@ -252,18 +278,15 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     const int H = tb.n_hand, M = tb.n_markers, NQ = H + M;
     const int Hpad = (H + 31) & ~31;           // both clouds are padded with far points to whole 32-point matrix tiles
     // phase 2 layout: the hand tile sits at the arena's end; its A-operand image (1 KB per 32 vertices) and the normals in front of
-    // it when they fit (H <= ~830; beyond, every wave builds the hand's A operands itself)
+    // it (they fit for H <= GLF_MAX_HAND, checked by the host: larger hand tables take grasp_loss_fwd_kernel)
     const int h_tiles = Hpad >> 5;
-    const int hand_off = (SM_TOTAL - NNF_TILE_FLOATS(Hpad)) & ~3;
-    const int nrm_floats = (H * 3 + 3) & ~3;
-    const bool a_image = h_tiles * 256 + nrm_floats <= hand_off;
+    const int hand_off = glf_hand_off(H);
     float* const sHand = smem + hand_off;
     float* const sAimg = smem;
-    float* const sNrm = smem + (a_image ? h_tiles * 256 : 0);
+    float* const sNrm = smem + h_tiles * 256;
     const float* vb = verts + (size_t)b * V * 3;
     const float* ob = obj + (size_t)b * O * 3;
     const float* onb = obj_n + (size_t)b * O * 3;
-    const int wave = tid >> 6, lane = tid & 63;
     GL_T0();
 
     // the lane's object points (O <= GL_TILE = GL_OPL * GL_THREADS): requested first, together with the query gathers below, and
@@ -331,9 +354,12 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     __syncthreads();
     GL_T(1);
 
+    // Register budget (168 per lane at three blocks per CU): the matrix-core pass holds 2 x 16 accumulators, the queries' B operands
+    // (32) and the sorted triples (40); what it does not read is kept out of its live range -- the framed query coordinates are
+    // formed again after it (same subtraction, same bits), the per-lane sums start after it, the sums of the first direction are
+    // folded to their wave partials before the second direction starts (the order of the additions is unchanged), frames and scales
+    // are scalar (nnf_uniform), and the wave reductions use immediate lane patterns (gl_wave_sum_lane0).
     float sums[GL_NSUM];
-#pragma unroll
-    for (int i = 0; i < GL_NSUM; ++i) sums[i] = 0.f;
 
     // ---- x -> y : every hand vertex / marker finds its nearest object point -------------------------------
     {
@@ -341,8 +367,6 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
         int c1[GL_NQ], c2[GL_NQ], bi[GL_NQ];
 #pragma unroll
         for (int i = 0; i < GL_NQ; ++i) { cx[i] = qx[i] - fo.cx; cy[i] = qy[i] - fo.cy; cz[i] = qz[i] - fo.cz; }
-#pragma unroll
-        for (int i = 0; i < GL_NQ; ++i) { best[i] = INFINITY; bi[i] = 0; }
         // approximate pass on the matrix cores (f16-split operands, nn_fast.h), exact pass on the two candidate chunks.  The four
         // waves scan the same 64 object tiles: their A operands are built ONCE per block, 16 tiles (16 KB) at a time, into the LDS
         // the hand tile will take afterwards (a wave rebuilding all of them itself spent a quarter of this scan's instructions there)
@@ -350,6 +374,7 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
             const float rq = fq.rp + fmaxf(fabsf(fq.cx - fo.cx), fmaxf(fabsf(fq.cy - fo.cy), fabsf(fq.cz - fo.cz)));
             const NnfScales ko = nnf_scales(fo.rp, rq);
             // query tile (i, hh) of this wave starts at query wave*64 + hh*32 + i*256: all-padding tiles are skipped
+            const int wave = nnf_again(tid) >> 6, lane = nnf_again(tid) & 63;
             unsigned act = 0;
 #pragma unroll
             for (int i = 0; i < GL_NQ; ++i)
@@ -376,6 +401,14 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
             nnf_mfma_end<GL_NQ>(st, ko, m1, m2, m3, c1, c2);
         }
         GL_T(2);
+#pragma unroll
+        for (int i = 0; i < GL_NQ; ++i) {
+            asm volatile("" : "+v"(qx[i]), "+v"(qy[i]), "+v"(qz[i]));     // not the same value to the compiler: cx.. do not stay live above
+            cx[i] = qx[i] - fo.cx; cy[i] = qy[i] - fo.cy; cz[i] = qz[i] - fo.cz;
+            best[i] = INFINITY; bi[i] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < GL_NSUM; ++i) sums[i] = 0.f;
         nnf_resolve<GL_NQ, true>(sObj, Opad / NNF_CH, fo, 0, cx, cy, cz, qx, qy, qz, m1, m2, m3, c1, c2, best, bi);
         GL_T(3);
 #pragma unroll
@@ -416,6 +449,14 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     for (int i = tid; i < tb.n_foot; i += GL_THREADS)
         sums[2] += fabsf(PRE ? uniq_rows[((size_t)b * tb.n_unique + tb.foot_slot[i]) * 3 + 2] : vb[tb.foot_ids[i] * 3 + 2]);
 
+    // sums 0-3, 5, 6, 8, 10, 11 are complete: fold them to wave partials now (4, 7, 9 belong to the second direction)
+#pragma unroll
+    for (int i = 0; i < GL_NSUM; ++i) {
+        if (i == 4 || i == 7 || i == 9) continue;
+        const float v = gl_wave_sum_lane0(sums[i]);
+        if ((nnf_again(tid) & 63) == 0) red[__builtin_amdgcn_readfirstlane(nnf_again(tid) >> 6)][i] = v;
+    }
+    sums[4] = 0.f; sums[7] = 0.f; sums[9] = 0.f;
     GL_T(4);
     // ---- hand normals (area-weighted, ascending face order) into the LDS space the object tile no longer needs ----
     // The normals gather three corners per incident face.  When the mesh's faces join vertices that are far apart in memory
@@ -434,10 +475,10 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     __syncthreads();                          // every wave is done with the object tile and its A-operand image: phase 2 of the arena
 #pragma unroll
     for (int i = 0; i < GL_NQ; ++i) {
-        const int q = tid + i * GL_THREADS;
+        const int q = nnf_again(tid) + i * GL_THREADS;
         if (q < H) nnf_store_point(sHand, q, qx[i], qy[i], qz[i], fh);
     }
-    for (int q = H + tid; q < Hpad; q += GL_THREADS) nnf_store_point(sHand, q, NN_FAR, NN_FAR, NN_FAR, fh);
+    for (int q = H + nnf_again(tid); q < Hpad; q += GL_THREADS) nnf_store_point(sHand, q, NN_FAR, NN_FAR, NN_FAR, fh);
     if (PRE) {
         const float* hn = hand_normals + (size_t)b * H * 3;
         for (int i = tid; i < H * 3; i += GL_THREADS) sNrm[i] = hn[i];
@@ -467,10 +508,12 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     // per block into the rest of the LDS space the object tile no longer needs (1 KB per 32 hand vertices, after the normals),
     // with one scale for the whole block: every object point is within fo.rp of the object frame's centre.
     const NnfScales kh = nnf_scales(fh.rp, fo.rp * 1.0001f + fmaxf(fabsf(fo.cx - fh.cx), fmaxf(fabsf(fo.cy - fh.cy), fabsf(fo.cz - fh.cz))));
-    if (a_image) __syncthreads();             // the hand tile is complete
-    if (a_image)
-        for (int t = tid >> 6; t < h_tiles; t += GL_THREADS / 64)
-            reinterpret_cast<nn_h8*>(sAimg)[t * 64 + (tid & 63)] = nnf_build_A(sHand, Hpad, t, tid & 63, kh);
+    __syncthreads();                          // the hand tile is complete
+    {
+        const int t2 = nnf_again(tid);
+        for (int t = t2 >> 6; t < h_tiles; t += GL_THREADS / 64)
+            reinterpret_cast<nn_h8*>(sAimg)[t * 64 + (t2 & 63)] = nnf_build_A(sHand, Hpad, t, t2 & 63, kh);
+    }
     __syncthreads();
 
     GL_T(5);
@@ -490,19 +533,22 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
             for (int i = 0; i < GLF_NO; ++i)
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh)
-                    if (k0 + wave * 64 + hh * 32 + i * GL_THREADS < O) act |= 1u << (2 * i + hh);
+                    if (k0 + (nnf_again(tid) >> 6) * 64 + hh * 32 + i * GL_THREADS < O) act |= 1u << (2 * i + hh);
             NnfMfmaState<GLF_NO> st;
             nnf_mfma_begin<GLF_NO>(st, kh, cx, cy, cz);
-            if (a_image) nnf_mfma_tiles<GLF_NO, true, true>(st, sAimg, Hpad / NNF_CH, 0, h_tiles, 0, kh, act);
-            else nnf_mfma_tiles<GLF_NO, false, true>(st, sHand, Hpad / NNF_CH, 0, h_tiles, 0, kh, act);
+            nnf_mfma_tiles<GLF_NO, true, true>(st, sAimg, Hpad / NNF_CH, 0, h_tiles, 0, kh, act);
             nnf_mfma_end<GLF_NO>(st, kh, m1, m2, m3, c1, c2);
         }
 #pragma unroll
-        for (int i = 0; i < GLF_NO; ++i) { best[i] = INFINITY; bj[i] = 0; }
+        for (int i = 0; i < GLF_NO; ++i) {
+            asm volatile("" : "+v"(ox[i]), "+v"(oy[i]), "+v"(oz[i]));
+            cx[i] = ox[i] - fh.cx; cy[i] = oy[i] - fh.cy; cz[i] = oz[i] - fh.cz;
+            best[i] = INFINITY; bj[i] = 0;
+        }
         nnf_resolve<GLF_NO, true>(sHand, Hpad / NNF_CH, fh, 0, cx, cy, cz, ox, oy, oz, m1, m2, m3, c1, c2, best, bj);
 #pragma unroll
         for (int i = 0; i < GLF_NO; ++i) {
-            const int k = k0 + tid + i * GL_THREADS;
+            const int k = k0 + nnf_again(tid) + i * GL_THREADS;
             if (k >= O) continue;
             const int j = bj[i];
             float hx, hy, hz;
@@ -520,12 +566,12 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     }
 
     GL_T(6);
-    // ---- per-candidate means: wave shuffles, then the four wave partials in wave order ---------------------
+    // ---- per-candidate means: wave sums, then the four wave partials in wave order ---------------------
 #pragma unroll
     for (int i = 0; i < GL_NSUM; ++i) {
-        float v = sums[i];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if (lane == 0) red[wave][i] = v;
+        if (!(i == 4 || i == 7 || i == 9)) continue;
+        const float v = gl_wave_sum_lane0(sums[i]);
+        if ((nnf_again(tid) & 63) == 0) red[__builtin_amdgcn_readfirstlane(nnf_again(tid) >> 6)][i] = v;
     }
     __syncthreads();
     if (tid == 0) {
@@ -717,7 +763,7 @@ extern "C" int saga_grasp_loss_fwd(const saga_model_t* m, const saga_grasp_table
                        hand_normals && h2o_marker && h2o_signed && o2h_signed && idx_m2o && idx_h2o && idx_o2h,
                    "saga_grasp_loss_fwd: null buffer");
     void* prof = saga_prof_begin(SAGA_PROF_GRASP_FWD, stream);
-    if (O <= GL_TILE)
+    if (O <= GL_TILE && glf_hand_fits(tb->n_hand))
         grasp_loss_fwd_fast_kernel<false><<<B, GL_THREADS, 0, (hipStream_t)stream>>>(*tb, verts, m->vf_ptr, m->vf_tri, obj,
                                                                               obj_normals, markers_target, c_markers, c_object, terms,
                                                                               markers_rec, hand_rec, hand_normals, h2o_marker,
@@ -732,6 +778,9 @@ extern "C" int saga_grasp_loss_fwd(const saga_model_t* m, const saga_grasp_table
     return 0;
 }
 
+// whether these tables and this object size take grasp_loss_fwd_fast_kernel (saga_fit_step asks before it runs the ring kernel)
+int saga_grasp_loss_fast_ok(const saga_grasp_tables_t* tb, int O) { return tb && O > 0 && O <= GL_TILE && glf_hand_fits(tb->n_hand); }
+
 // saga_fit_step after saga_launch_skin_fwd_cand: uniq_rows and hand_normals are inputs (see the kernel).
 // O <= GL_TILE only (the caller falls back to saga_grasp_loss_fwd otherwise).
 int saga_grasp_loss_fwd_pre(const saga_model_t* m, const saga_grasp_tables_t* tb, const float* obj, const float* obj_normals,
@@ -743,7 +792,7 @@ int saga_grasp_loss_fwd_pre(const saga_model_t* m, const saga_grasp_tables_t* tb
     SAGA_CHECK_DEVICE(m, "saga_grasp_loss_fwd_pre");
     int rc = check_tables(tb);
     if (rc) return rc;
-    SAGA_CHECK_ARG(B >= 0 && O > 0 && O <= GL_TILE, "saga_grasp_loss_fwd_pre: bad sizes B=%d O=%d", B, O);
+    SAGA_CHECK_ARG(B >= 0 && saga_grasp_loss_fast_ok(tb, O), "saga_grasp_loss_fwd_pre: bad sizes B=%d O=%d n_hand=%d", B, O, tb->n_hand);
     if (B == 0) return 0;
     SAGA_CHECK_ARG(obj && obj_normals && markers_target && c_markers && c_object && terms && markers_rec && hand_rec && hand_normals &&
                        uniq_rows && h2o_marker && h2o_signed && o2h_signed && idx_m2o && idx_h2o && idx_o2h,

@@ -38,6 +38,18 @@
 
 struct NnfFrame { float cx, cy, cz, rp; };
 
+// An integer again, as a value the compiler cannot connect to its earlier uses: index arithmetic formed from it (tid >> 6, tid & 63,
+// chunk offsets) is recomputed where it is needed -- one or two integer operations -- instead of being kept live, and spilled to
+// scratch, across a matrix-core pass that needs every register.
+__device__ __forceinline__ int nnf_again(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// a value every lane of the wave holds identically, moved to a scalar register (gfx950 has no scalar float ALU: whatever is computed
+// from LDS reads or other uniform floats otherwise lives in a vector register per lane for as long as it is live)
+__device__ __forceinline__ float nnf_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
 __device__ __forceinline__ float nnf_axis_centre(float lo, float hi) {
     if (lo > 0.f && hi <= 2.f * lo) return 0.5f * (lo + hi);
     if (hi < 0.f && lo >= 2.f * hi) return 0.5f * (lo + hi);
@@ -71,8 +83,8 @@ __device__ __forceinline__ NnfFrame nnf_frame_from_box(float (&lo)[3], float (&h
         r2 = fmaf(r, r, r2);
     }
     NnfFrame f;
-    f.cx = c[0]; f.cy = c[1]; f.cz = c[2];
-    f.rp = sqrtf(r2) * 1.0001f;
+    f.cx = nnf_uniform(c[0]); f.cy = nnf_uniform(c[1]); f.cz = nnf_uniform(c[2]);
+    f.rp = nnf_uniform(sqrtf(r2) * 1.0001f);
     return f;
 }
 
@@ -89,7 +101,7 @@ __device__ __forceinline__ NnfFrame nnf_frame(const float* __restrict__ src, int
     return nnf_frame_from_box(lo, hi, sred, tid, nthreads);
 }
 
-__device__ __forceinline__ void nnf_store_point(float* __restrict__ s, int k, float x, float y, float z, const NnfFrame& f) {
+__device__ __forceinline__ void nnf_store_point(float* __restrict__ s, int k, float x, float y, float z, const NnfFrame f) {
     const float px = x - f.cx, py = y - f.cy, pz = z - f.cz;       // exact for points inside the frame's box
     const float w = __builtin_fmaf(pz, pz, __builtin_fmaf(py, py, px * px));
     float* d = s + (k / NNF_CH) * NNF_CSTRIDE + ((k % NNF_CH) >> 1) * 8 + (k & 1);
@@ -97,7 +109,7 @@ __device__ __forceinline__ void nnf_store_point(float* __restrict__ s, int k, fl
 }
 
 // Stage cnt points (xyz rows) as a framed tile padded to a multiple of NNF_CH with far points.  Caller synchronises.
-__device__ __forceinline__ int nnf_stage_tile(float* __restrict__ s, const float* __restrict__ src, int cnt, const NnfFrame& f,
+__device__ __forceinline__ int nnf_stage_tile(float* __restrict__ s, const float* __restrict__ src, int cnt, const NnfFrame f,
                                               int tid, int nthreads) {
     const int cnt_pad = (cnt + NNF_CH - 1) / NNF_CH * NNF_CH;
     for (int k = tid; k < cnt_pad; k += nthreads) {
@@ -109,7 +121,7 @@ __device__ __forceinline__ int nnf_stage_tile(float* __restrict__ s, const float
 }
 
 // original coordinates of point j of a framed tile (bit-exact)
-__device__ __forceinline__ void nnf_tile_point(const float* __restrict__ s, const NnfFrame& f, int j, float& x, float& y, float& z) {
+__device__ __forceinline__ void nnf_tile_point(const float* __restrict__ s, const NnfFrame f, int j, float& x, float& y, float& z) {
     const float* p = s + (j / NNF_CH) * NNF_CSTRIDE + ((j % NNF_CH) >> 1) * 8 + (j & 1);
     x = __builtin_fmaf(-0.5f, p[0], f.cx); y = __builtin_fmaf(-0.5f, p[2], f.cy); z = __builtin_fmaf(-0.5f, p[4], f.cz);
 }
@@ -237,10 +249,11 @@ __device__ __forceinline__ void nnf_split16(float x, _Float16& hi, _Float16& lo)
 struct NnfScales { float sa, sq, S, inv_S; };
 __device__ __forceinline__ NnfScales nnf_scales(float rp, float rq) {
     NnfScales k;
-    k.sa = nnf_pow2_scale(2.f * rp);
-    k.sq = fminf(nnf_pow2_scale(rq), nnf_pow2_scale(rp));
-    k.S = k.sa * k.sq;
-    k.inv_S = 1.f / k.S;
+    // rp, rq are wave-uniform wherever this is called (frames, block- or wave-wide maxima): keep the scales in scalar registers
+    k.sa = nnf_uniform(nnf_pow2_scale(2.f * rp));
+    k.sq = nnf_uniform(fminf(nnf_pow2_scale(rq), nnf_pow2_scale(rp)));
+    k.S = nnf_uniform(k.sa * k.sq);
+    k.inv_S = nnf_uniform(1.f / k.S);
     return k;
 }
 
@@ -379,7 +392,7 @@ __device__ __forceinline__ void nnf_scan_mfma_core(const float* __restrict__ s, 
 
 // Stand-alone form: scales from this wave's own queries, A operands built on the fly.
 template <int NQ>
-__device__ __forceinline__ void nnf_scan_mfma(const float* __restrict__ s, int n_chunks, const NnfFrame& f, const float (&qx)[NQ],
+__device__ __forceinline__ void nnf_scan_mfma(const float* __restrict__ s, int n_chunks, const NnfFrame f, const float (&qx)[NQ],
                                               const float (&qy)[NQ], const float (&qz)[NQ], float (&m1)[NQ], float (&m2)[NQ],
                                               float (&m3)[NQ], int (&c1)[NQ], int (&c2)[NQ]) {
     float rq = 0.f;
@@ -392,7 +405,7 @@ __device__ __forceinline__ void nnf_scan_mfma(const float* __restrict__ s, int n
 
 // exact evaluation of one chunk for one query (original coordinates o*), index order, strict '<'.  Two points per packed
 // instruction; every packed lane performs the IEEE operation of nn_dist2, so the values are those of the scalar chain.
-__device__ __forceinline__ void nnf_exact_chunk(const float* __restrict__ s, const NnfFrame& f, int ch, int base, float ox, float oy,
+__device__ __forceinline__ void nnf_exact_chunk(const float* __restrict__ s, const NnfFrame f, int ch, int base, float ox, float oy,
                                                 float oz, float& best, int& bi) {
 #pragma clang fp contract(off)
     const float4* t = reinterpret_cast<const float4*>(s + ch * NNF_CSTRIDE);
@@ -418,7 +431,7 @@ __device__ __forceinline__ void nnf_exact_chunk(const float* __restrict__ s, con
 // together (the slow path is a wave-wide loop).
 // MFMA_PASS: the chunk minima come from nnf_scan_mfma (its error bound replaces the vector pass's).
 template <int NQ, bool MFMA_PASS = false>
-__device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_chunks, const NnfFrame& f, int base,
+__device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_chunks, const NnfFrame f, int base,
                                             const float (&qx)[NQ], const float (&qy)[NQ], const float (&qz)[NQ],
                                             const float (&ox)[NQ], const float (&oy)[NQ], const float (&oz)[NQ],
                                             const float (&m1)[NQ], const float (&m2)[NQ], const float (&m3)[NQ],
