@@ -12,14 +12,20 @@ import torch
 from .chamfer_ref import chamfer_distance
 
 
-def point2point_signed(x, y, x_normals=None, y_normals=None, return_vector=False):
+def point2point_signed(x, y, x_normals=None, y_normals=None, return_vector=False, force_idx=None):
     """train_helper.py:17-86.  x [N,P1,D], y [N,P2,D] -> y2x_signed [N,P2], x2y_signed [N,P1],
-    yidx_near [N,P2] int32, xidx_near [N,P1] int32 (, y2x, x2y)."""
+    yidx_near [N,P2] int32, xidx_near [N,P1] int32 (, y2x, x2y).
+    ``force_idx`` = (yidx_near or None, xidx_near or None): neighbours given by the caller instead of searched -- for tests that
+    have shown another implementation's indices to differ from this search only at distance near-ties and want everything
+    downstream of the tie decision compared (no counterpart in the reference)."""
     N, P1, D = x.shape
     P2 = y.shape[1]
     if y.shape[0] != N or y.shape[2] != D:
         raise ValueError("y does not have the correct shape.")          # :52-53
     _, _, xidx_near, yidx_near = chamfer_distance(x.detach(), y.detach())  # :57 (distances discarded)
+    if force_idx is not None:
+        yidx_near = yidx_near if force_idx[0] is None else torch.as_tensor(force_idx[0]).to(yidx_near.dtype).reshape(yidx_near.shape)
+        xidx_near = xidx_near if force_idx[1] is None else torch.as_tensor(force_idx[1]).to(xidx_near.dtype).reshape(xidx_near.shape)
     xi = xidx_near.view(N, P1, 1).expand(N, P1, D).to(torch.long)        # :59
     x_near = y.gather(1, xi)                                             # :60
     yi = yidx_near.view(N, P2, 1).expand(N, P2, D).to(torch.long)        # :62

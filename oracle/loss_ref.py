@@ -35,13 +35,15 @@ def body_params(var, vposer_w, hand_ncomps=24):
 
 def loss_batched(bm, var, vposer_w, idx, body_markers, verts_object, normal_object,
                  contacts_object, contacts_markers, stage, only_rec=False, contact_loss='contact',
-                 hand_ncomps=24):
+                 hand_ncomps=24, force_idx=None):
     """Per-candidate losses [B] and loss_dict/counts as [B] tensors.
 
     bm: oracle.smplx_ref.SMPLXRef; var: dict of optimiser variables [B,.];
     idx: dict markers_143 / foot / rhand (long), v_weights [778];
     body_markers [B,143,3]; verts_object, normal_object [B,O,3];
     contacts_object [B,O]; contacts_markers [B,143].
+    force_idx: None, or {'idx_m2o', 'idx_h2o', 'idx_o2h'} -> neighbour indices to use instead of the search's
+    (geometry_ref.point2point_signed: tie decisions taken from the implementation under test).
     """
     bp = body_params(var, vposer_w, hand_ncomps)
     out = bm(**bp)
@@ -64,8 +66,10 @@ def loss_batched(bm, var, vposer_w, idx, body_markers, verts_object, normal_obje
     vo = verts_object.to(verts.dtype)
     no = normal_object.to(verts.dtype)
     # :183 -- normal_object lands in the x_normals slot (quirk a13q-i), y_normals=None
-    _o2h_marker, h2o_marker, _, _ = point2point_signed(markers_rec, vo, no)
-    o2h, h2o, _, _ = point2point_signed(rhand_rec, vo, nrm, no)                        # :184
+    fi = force_idx or {}
+    _o2h_marker, h2o_marker, _, idx_m2o = point2point_signed(markers_rec, vo, no, force_idx=(None, fi.get('idx_m2o')))
+    o2h, h2o, idx_o2h, idx_h2o = point2point_signed(rhand_rec, vo, nrm, no,
+                                                    force_idx=(fi.get('idx_o2h'), fi.get('idx_h2o')))   # :184
 
     loss_marker_contact = (h2o_marker.abs() * contacts_markers.view(B, -1)).mean(dim=1)   # :190
     loss_object_contact = (o2h.abs() * contacts_object.view(B, -1)).mean(dim=1)           # :191
@@ -104,7 +108,7 @@ def loss_batched(bm, var, vposer_w, idx, body_markers, verts_object, normal_obje
     }
     aux = {'markers_rec': markers_rec, 'rhand_rec': rhand_rec, 'rh_normals': nrm, 'h2o': h2o,
            'o2h': o2h, 'h2o_marker': h2o_marker, 'body_param': bp, 'vertices': verts,
-           'joints': out['joints']}
+           'joints': out['joints'], 'idx_m2o': idx_m2o, 'idx_h2o': idx_h2o, 'idx_o2h': idx_o2h}
     return total, loss_dict, counts, aux
 
 

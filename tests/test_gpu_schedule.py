@@ -302,3 +302,124 @@ def test_config1_full_schedule_against_oracle(body_model_dir):
     # stage 3 is chaotic on the synthetic inputs (oracle float32 vs float64: > 50 % apart): compare what the fit is judged by,
     # the loss level it settles at
     np.testing.assert_allclose(total[-100:].mean(axis=0), hist[-100:].mean(axis=0), rtol=0.35)
+
+
+def _oracle_from_state(bm64, vp, idx, d, packed_vars, stage, **kw):
+    """The fp64 oracle's loss, counts, aux and variable gradients evaluated FROM a packed variable state of the HIP path."""
+    from oracle import loss_ref
+    from saga_amd import _lib
+    var = {k: packed_vars[:, a:b].detach().cpu().double().clone().requires_grad_(True) for k, (a, b) in _lib.VAR_SLICES.items()}
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).double()
+    total, ld, cnt, aux = loss_ref.loss_batched(bm64, var, vp.weights_dict(torch.float64), idx, t(d['markers']), t(d['verts_o']),
+                                                t(d['normals_o']), t(d['oc']), t(d['mc']), stage, **kw)
+    total.sum().backward()
+    return total, ld, cnt, aux, var
+
+
+def _check_nn_indices(name, got_idx, q32, db32, ref_idx, q64, db64):
+    """NN indices of the fused kernel at a visited state.  (a) On the HIP path's OWN float32 points they equal the C oracle's
+    sequential strict-'<' scan bit for bit.  (b) Against the fp64 oracle (whose points differ by the 1e-5 m vertex tolerance) they
+    are equal except at near-ties: the oracle's two candidate distances then differ by less than the vertex tolerance allows."""
+    from oracle import chamfer_ref
+    _, want = chamfer_ref._scan(np.ascontiguousarray(q32), np.ascontiguousarray(db32))
+    assert np.array_equal(got_idx, want), '%s: %d of %d indices differ from the exact float32 scan' % (name, (got_idx != want).sum(), want.size)
+    diff = np.argwhere(got_idx != ref_idx)
+    for b, p in diff:
+        da = np.linalg.norm(q64[b, p] - db64[b, got_idx[b, p]])
+        dr = np.linalg.norm(q64[b, p] - db64[b, ref_idx[b, p]])
+        assert abs(da - dr) <= 4e-5, '%s: candidate %d point %d: index %d (d=%.9g) vs oracle %d (d=%.9g) is not a near-tie' % (
+            name, b, p, got_idx[b, p], da, ref_idx[b, p], dr)
+    return len(diff)
+
+
+def test_config1_teacher_forced_late_states_against_oracle(body_model_dir):
+    """the states a fit actually VISITS -- large poses, hand in contact, NN near-ties, non-zero collision
+    counts -- compared with the oracle at iteration-0 bars.  Two config-1 objects run the full 300/400/500 schedule on the HIP
+    path; at iterations 299 (stage 1), 699 (stage 2), 950 and 1199 (stage 3) the variables the HIP path holds BEFORE the
+    iteration are copied into the fp64 oracle, which evaluates THAT iteration: no trajectory, so no chaos.  Bars: the 10
+    loss_dict keys 1e-4 relative, the 4 counts +-2, NN indices exact (see _check_nn_indices), gradient rows 2e-3."""
+    from oracle import loss_ref
+    from saga_amd import _lib
+    from saga_amd.fitting import FittingOP, load_grasp_indices
+    from saga_amd.vposer import VPoserDecoder
+    res = _config1_inputs()
+    B, O = 2, res['verts_object'].shape[1]
+    d = dict(markers=res['markers_gen'][:B], mc=res['markers_contact_gen'][:B], oc=res['object_contact_gen'][:B],
+             verts_o=res['verts_object'][:B], normals_o=res['normal_object'][:B])
+    num_iter = (300, 400, 500)
+    checks = {299: 0, 699: 1, 950: 2, 1199: 2}
+    vp = VPoserDecoder(seed=0)
+    op = FittingOP({'batch_size': B, 'device': 'cuda', 'body_model_path': body_model_dir, 'vposer': vp, 'genders': ('male',),
+                    'num_iter': list(num_iter)})
+    real, state, cap = op.native_step, {'it': 0}, {}
+    H, M = op.tables.n_hand, op.tables.n_markers
+
+    def step(ss, prob, terms=None):
+        it = state['it']
+        state['it'] += 1
+        if it not in checks:
+            return real(ss, prob, terms)
+        assert checks[it] == ss
+        before = op.vars.clone()
+        out = real(ss, prob, terms)
+        w = lambda n, s, dt=torch.float32: op.workspace_view(n, O, s, dt).clone().cpu().numpy()
+        cap[it] = dict(vars=before, terms=terms.clone().cpu().numpy(), grad=w('grad', (B, _lib.VAR_STRIDE)), g_z=w('g_z', (B, 128)),
+                       idx_m2o=w('idx_m2o', (B, M), torch.int32), idx_h2o=w('idx_h2o', (B, H), torch.int32),
+                       idx_o2h=w('idx_o2h', (B, O), torch.int32), hand=w('hand_rec', (B, H, 3)), markers=out[1].clone().cpu().numpy(),
+                       h2o=w('h2o_signed', (B, H)), o2h=w('o2h_signed', (B, O)))
+        return out
+
+    op.native_step = step
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    op.fitting(cu(d['markers']), cu(d['oc']), cu(d['mc']), cu(d['verts_o']), cu(d['normals_o']), 'male')
+    assert sorted(cap) == sorted(checks)
+
+    idx_np = load_grasp_indices()
+    idx = {'markers_143': torch.from_numpy(idx_np['markers_143']), 'foot': torch.from_numpy(idx_np['foot']),
+           'rhand': torch.from_numpy(idx_np['rhand']), 'v_weights': torch.from_numpy(idx_np['rhand_weight'])}
+    bm64 = load_oracle_model(body_model_dir, B, dtype=torch.float64)
+    owned = {0: ['transl_rec', 'glo_rot_rec'], 1: ['betas', 'transl_rec', 'glo_rot_rec', 'vpose_rec'],
+             2: ['vpose_rec', 'hand_pose', 'eye_pose']}
+    obj64 = d['verts_o'].astype(np.float64)
+    seen_collisions, errs = 0, []
+    for it, ss in sorted(checks.items()):
+        c = cap[it]
+        total, ld, cnt, aux, var = _oracle_from_state(bm64, vp, idx, d, c['vars'], ss)
+        # the state is a visited one, not the seeded start: the body has moved and (stage 3) touches the object
+        assert np.abs(c['vars'][:, 96:99].cpu().numpy()).max() > 0.05
+        for i, k in enumerate(loss_ref.LOSS_KEYS):
+            np.testing.assert_allclose(c['terms'][:, i], ld[k].detach().numpy(), rtol=1e-4, atol=1e-9, err_msg='%s at iteration %d' % (k, it))
+        for i, k in enumerate(loss_ref.COUNT_KEYS):
+            assert np.abs(c['terms'][:, 10 + i] - cnt[k].numpy()).max() <= 2, (k, it, c['terms'][:, 10 + i], cnt[k])
+        seen_collisions += int(c['terms'][:, 10].sum() + c['terms'][:, 11].sum())
+        assert np.abs(c['markers'] - aux['markers_rec'].detach().numpy()).max() < 1e-5
+        assert np.abs(c['hand'] - aux['rhand_rec'].detach().numpy()).max() < 1e-5
+        hand64, mk64 = aux['rhand_rec'].detach().numpy(), aux['markers_rec'].detach().numpy()
+        n_ties = _check_nn_indices('markers->object @%d' % it, c['idx_m2o'], c['markers'], d['verts_o'], aux['idx_m2o'].numpy(), mk64, obj64)
+        n_ties += _check_nn_indices('hand->object @%d' % it, c['idx_h2o'], c['hand'], d['verts_o'], aux['idx_h2o'].numpy(), hand64, obj64)
+        n_ties += _check_nn_indices('object->hand @%d' % it, c['idx_o2h'], d['verts_o'], c['hand'], aux['idx_o2h'].numpy(), obj64, hand64)
+        # signed distances: equal to 1e-5 m except where the sign itself is decided by a dot product at rounding level
+        n_flips = 0
+        for key, ref in (('h2o', aux['h2o']), ('o2h', aux['o2h'])):
+            a, r = c[key], ref.detach().numpy()
+            bad = np.abs(a - r) > 2e-5
+            assert bad.sum() <= 2 and np.all(np.abs(np.abs(a[bad]) - np.abs(r[bad])) <= 2e-5), (key, it, int(bad.sum()))
+            n_flips += int(bad.sum())
+        if n_ties:
+            # a neighbour that differs at a verified near-tie sends its gradient along another unit vector (and, object -> hand,
+            # into another hand vertex): gradients are compared downstream of the SAME tie decisions, the HIP path's
+            total, ld, cnt, aux, var = _oracle_from_state(bm64, vp, idx, d, c['vars'], ss, force_idx={k_: c[k_] for k_ in ('idx_m2o', 'idx_h2o', 'idx_o2h')})
+            for i, k in enumerate(loss_ref.LOSS_KEYS):
+                np.testing.assert_allclose(c['terms'][:, i], ld[k].detach().numpy(), rtol=1e-4, atol=1e-9, err_msg='%s at iteration %d (forced ties)' % (k, it))
+        for k in owned[ss]:
+            a, b_ = _lib.VAR_SLICES[k]
+            got = c['g_z'][:, :32] if k == 'vpose_rec' else c['grad'][:, a:b_]
+            if k == 'vpose_rec':
+                got = got + 2e-4 / 32 * c['vars'][:, a:b_].cpu().numpy()       # the regulariser's gradient is added in the Adam kernel
+            e = np.abs(got - var[k].grad.numpy()).max() / np.abs(var[k].grad.numpy()).max()
+            print('   gradient of %s @%d: rel err %.3g (|g|max %.3g, sign flips %d)' % (k, it, e, np.abs(var[k].grad.numpy()).max(), n_flips))
+            errs.append(('gradient of %s at iteration %d' % (k, it), e))
+        print('teacher-forced @%d (stage %d): losses 1e-4, counts %s, %d near-tie indices' % (it, ss, c['terms'][:, 10:14].tolist(), n_ties))
+    for name, e in errs:
+        assert e < 2e-3, (name, e)
+    assert seen_collisions > 0, 'no visited state had a vertex in collision: the late-state check is not exercising the collision terms'
