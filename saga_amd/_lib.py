@@ -180,6 +180,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    if lib.saga_version() <= 0 and not os.environ.get('SAGA_ALLOW_EXPERIMENT_LIB'):
+        # -DSAGA_EXPERIMENT_BUILD: the timing experiments of scripts/exp, several of which give wrong results by design
+        raise RuntimeError('saga_amd: %s is an EXPERIMENT build (saga_version() = %d): not a library to compute with. '
+                           'scripts/exp sets SAGA_ALLOW_EXPERIMENT_LIB=1 to load one.' % (LIB_PATH, lib.saga_version()))
     _lib = lib
     return lib
 

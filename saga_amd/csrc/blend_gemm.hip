@@ -101,7 +101,7 @@ __device__ __forceinline__ void gemm_wait_lgkm(gemm_f4& a, gemm_f4& b) {
     else static_assert(N == 0, "unsupported lgkmcnt");
 }
 
-#ifdef GEMM_EXP_TRACE      // investigation build only: per-block time stamps of the persistent forward launch (scripts/exp/gemm_trace.py)
+#if defined(SAGA_EXPERIMENT_BUILD) && defined(GEMM_EXP_TRACE)      // investigation build only: per-block time stamps of the persistent forward launch (scripts/exp/gemm_trace.py)
 #define GEMM_TRACE_STRIDE 96
 __device__ unsigned long long gemm_trace_buf[1024 * GEMM_TRACE_STRIDE];
 extern "C" int saga_debug_gemm_trace(unsigned long long* host, size_t n) {
@@ -141,13 +141,13 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     // n_tiles_x > gridDim.x: a PERSISTENT launch -- a block walks the x tiles bx = blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x a
     // multiple of 8, so a block's tiles stay on its XCD's share of the ownership map below); 0: one tile per block
     if (n_tiles_x == 0) n_tiles_x = gridDim.x;
-#ifdef GEMM_EXP_STAGGER
+#if defined(SAGA_EXPERIMENT_BUILD) && defined(GEMM_EXP_STAGGER)
     // The two blocks of a CU start together and every tile takes the same time, so their prologues / epilogues (no MFMAs) coincide
     // for the whole launch: the second half of the blocks (the second block of every CU) starts GEMM_EXP_STAGGER x 1,024 cycles late
     if (n_tiles_x > (int)gridDim.x && blockIdx.x >= gridDim.x / 2)
         for (int i = 0; i < GEMM_EXP_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
 #endif
-#ifdef GEMM_EXP_TRACE
+#if defined(SAGA_EXPERIMENT_BUILD) && defined(GEMM_EXP_TRACE)
     if (EPI == 0 && WT == 2 && threadIdx.x == 0 && n_tiles_x > (int)gridDim.x)
         gemm_trace_buf[blockIdx.x * GEMM_TRACE_STRIDE] =
             (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32);
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
                 if (NST > 2 && t + NST - 2 < T) gemm_wait_vmcnt<(NST - 2) * 2 * PPW>();
                 else gemm_wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();       // everyone's pieces have; everyone is done reading stage (t-1) % NST
-#ifdef GEMM_EXP_TRACE
+#if defined(SAGA_EXPERIMENT_BUILD) && defined(GEMM_EXP_TRACE)
                 if (t == 0) { GEMM_STAMP(2 + 6 * trace_i) }
 #endif
                 // fragment reads as asm (see gemm_lds_read128), all of them before the LDS-DMA of a later tile
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
                     for (int q = 0; q < 4; ++q) xq[EPI == 3 ? mt : 0][EPI == 3 ? nt : 0][q] = *reinterpret_cast<const float4*>(xp + nt * 32 + 8 * q);
             }
         }
-#ifdef GEMM_EXP_TRACE
+#if defined(SAGA_EXPERIMENT_BUILD) && defined(GEMM_EXP_TRACE)
         GEMM_STAMP(4 + 6 * trace_i)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         GEMM_STAMP(5 + 6 * trace_i)
@@ -396,14 +396,14 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
                         v.x = x.x > 0.f ? v.x : 0.2f * v.x; v.y = x.y > 0.f ? v.y : 0.2f * v.y;
                         v.z = x.z > 0.f ? v.z : 0.2f * v.z; v.w = x.w > 0.f ? v.w : 0.2f * v.w;
                     }
-#ifdef GEMM_EXP_NO_STORE        // timing experiment: what the epilogue's stores cost (wrong results)
+#if defined(SAGA_EXPERIMENT_BUILD) && defined(GEMM_EXP_NO_STORE)        // timing experiment: what the epilogue's stores cost (wrong results)
                     if (v.x == 123.456f)
 #endif
                     *reinterpret_cast<float4*>(cp + nt * 32 + 8 * q) = v;
                 }
             }
         }
-#ifdef GEMM_EXP_TRACE
+#if defined(SAGA_EXPERIMENT_BUILD) && defined(GEMM_EXP_TRACE)
         GEMM_STAMP(6 + 6 * trace_i)
         ++trace_i;
 #endif

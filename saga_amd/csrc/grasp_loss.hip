@@ -219,7 +219,7 @@ __global__ __launch_bounds__(GL_THREADS) void grasp_loss_fwd_kernel(
     }
 }
 
-#ifdef GL_PHASE_TIMING
+#if defined(SAGA_EXPERIMENT_BUILD) && defined(GL_PHASE_TIMING)
 __device__ unsigned long long gl_phase[8];
 extern "C" int saga_debug_read_phases(unsigned long long* out) {
     unsigned long long z[8] = {0};
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
             constexpr int IMG_TILES = 16;
             static_assert(IMG_TILES * 256 <= NNF_TILE_FLOATS(GL_MAX_HAND), "the A-operand image lives behind the object tile");
             const int o_tiles = Opad >> 5;
-#ifdef GL_EXP_XY_PRIVATE        // timing experiment (scripts/exp): every wave builds its own A operands, no rounds, no barriers
+#if defined(SAGA_EXPERIMENT_BUILD) && defined(GL_EXP_XY_PRIVATE)        // timing experiment (scripts/exp): every wave builds its own A operands, no rounds, no barriers
             nnf_mfma_tiles<GL_NQ, false, true>(st, sObj, Opad / NNF_CH, 0, o_tiles, 0, ko, act);
 #else
             for (int r = 0; r < o_tiles; r += IMG_TILES) {
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     // (touch_verts: set by the host from the model's faces), those are ~14k scattered 12-B reads per candidate that miss L2
     // (4x the bytes the candidate has).  Touching every 128-B line of the candidate's vertex block once, coalesced, brings
     // the block (126 KB) into L2 first.
-#ifndef GL_EXP_NO_NORMALS
+#if !(defined(SAGA_EXPERIMENT_BUILD) && defined(GL_EXP_NO_NORMALS))
     if (!PRE && touch_verts) {
         const int n_lines = (V * 3 + 31) / 32;
         for (int l = tid; l < n_lines; l += GL_THREADS) {
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
         float nr[NVL][3];
 #pragma unroll
         for (int r = 0; r < NVL; ++r) hv[r] = (tid + r * GL_THREADS < H) ? tb.hand_ids[tid + r * GL_THREADS] : -1;
-#ifdef GL_EXP_NO_NORMALS            // timing experiment only (scripts/exp): what the kernel costs without the normals' gathers
+#if defined(SAGA_EXPERIMENT_BUILD) && defined(GL_EXP_NO_NORMALS)            // timing experiment only (scripts/exp): what the kernel costs without the normals' gathers
 #pragma unroll
         for (int r = 0; r < NVL; ++r) { nr[r][0] = 0.f; nr[r][1] = 0.f; nr[r][2] = 1.f; }
 #else

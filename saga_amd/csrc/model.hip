@@ -25,7 +25,17 @@ int saga_check_device(int device, const char* what) {
                    "(make that device current -- hipSetDevice / torch.cuda.device -- and pass one of its streams)", what, device, cur);
     return 0;
 }
-extern "C" int saga_version(void) { return 100; }
+// Release builds report a positive version.  A library compiled with -DSAGA_EXPERIMENT_BUILD -- the only way the timing
+// experiments in the sources (-DGEMM_EXP_*, -DDS_EXP_*, -DGL_EXP_*, -DGL_PHASE_TIMING: several give WRONG results by design)
+// compile at all -- reports the negated version, and saga_amd._lib.load() refuses it outside scripts/exp.
+#define SAGA_VERSION 300
+extern "C" int saga_version(void) {
+#ifdef SAGA_EXPERIMENT_BUILD
+    return -SAGA_VERSION;
+#else
+    return SAGA_VERSION;
+#endif
+}
 
 int saga_noalloc_init_device(int device);
 

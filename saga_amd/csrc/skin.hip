@@ -495,7 +495,7 @@ __global__ __launch_bounds__(DS_THREADS, 4) void skin_bwd_sparse_kernel(
     __shared__ __attribute__((aligned(16))) float sX[DS_VR * 6];     // phase 1/2: [vertex][g.xyz, p.xyz]; phase 3: [12][DS_THREADS]
     __shared__ __attribute__((aligned(16))) float sA[NJ * 12];
     __shared__ float sG[DS_THREADS / 64][4];
-#ifdef DS_EXP_PAD       // timing experiment: extra LDS per block (occupancy of a replicated joint table)
+#if defined(SAGA_EXPERIMENT_BUILD) && defined(DS_EXP_PAD)       // timing experiment: extra LDS per block (occupancy of a replicated joint table)
     __shared__ float sPad[DS_EXP_PAD];
     if (V < 0) sPad[threadIdx.x] = (float)Npad;
     if (V < -1) g_vposed[threadIdx.x] = sPad[threadIdx.x + 1];
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(DS_THREADS, 4) void skin_bwd_sparse_kernel(
 #pragma unroll
             for (int k = 0; k < 9; ++k) T[k] = 0.f;
             if (KW4) {
-#ifdef DS_EXP_P1        // timing experiment: conflict-free joint reads (wrong results)
+#if defined(SAGA_EXPERIMENT_BUILD) && defined(DS_EXP_P1)        // timing experiment: conflict-free joint reads (wrong results)
                 const int jj[4] = {(tid & 15) + (ji[i].x & 16), (tid & 15) + (ji[i].y & 16), (tid & 15) + (ji[i].z & 16), (tid & 15) + (ji[i].w & 16)};
 #else
                 const int jj[4] = {ji[i].x, ji[i].y, ji[i].z, ji[i].w};
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(DS_THREADS, 4) void skin_bwd_sparse_kernel(
             for (int u = 0; u < 4; ++u) en[u] = e[(size_t)(cn + u) * DS_THREADS];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-#ifdef DS_EXP_P2        // timing experiment: conflict-free row reads (wrong results)
+#if defined(SAGA_EXPERIMENT_BUILD) && defined(DS_EXP_P2)        // timing experiment: conflict-free row reads (wrong results)
                 const float2* row = reinterpret_cast<const float2*>(sX + (((cur[u].x & 480) + tid) & 511) * 6);
 #else
                 const float2* row = reinterpret_cast<const float2*>(sX + cur[u].x * 6);

@@ -1,6 +1,8 @@
 """Phase timing of skin_bwd_dA_kernel (s_memtime stamps, cycles per wave per step).  Needs a build of the library with
 -DDA_PHASE_TIMING (every .hip of saga_amd/csrc compiled with the Makefile's flags plus that define, linked to e.g.
 scripts/exp/libsaga_DAT.so) and  SAGA_HIP_LIB=scripts/exp/libsaga_DAT.so python scripts/exp/da_phases.py"""
+import os
+os.environ.setdefault('SAGA_ALLOW_EXPERIMENT_LIB', '1')      # these scripts load -DSAGA_EXPERIMENT_BUILD libraries (saga_amd/_lib.py refuses them otherwise)
 import ctypes, os, sys, tempfile
 sys.path.insert(0, os.getcwd())
 import torch

@@ -1,6 +1,8 @@
 """Per-block timeline of the persistent forward blend GEMM (library built with -DGEMM_EXP_TRACE: scripts/exp/build_variant.sh tr
 -DGEMM_EXP_TRACE; run with SAGA_HIP_LIB=build/variants/libsaga_tr.so): which blocks share a CU, and whether their prologues /
 epilogues coincide."""
+import os
+os.environ.setdefault('SAGA_ALLOW_EXPERIMENT_LIB', '1')      # these scripts load -DSAGA_EXPERIMENT_BUILD libraries (saga_amd/_lib.py refuses them otherwise)
 import os, sys, tempfile, ctypes, collections
 os.environ.setdefault('SAGA_GEMM_PERSIST', '-1')     # the stamps are taken in the persistent form of the launch (two blocks per CU walking the tiles)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -1,4 +1,6 @@
 """Phase timing of the fused loss kernel: needs a build of the library with -DGL_PHASE_TIMING loaded through SAGA_HIP_LIB."""
+import os
+os.environ.setdefault('SAGA_ALLOW_EXPERIMENT_LIB', '1')      # these scripts load -DSAGA_EXPERIMENT_BUILD libraries (saga_amd/_lib.py refuses them otherwise)
 import ctypes, os, sys, json, subprocess
 sys.path.insert(0, os.getcwd())
 import torch, tempfile

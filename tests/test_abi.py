@@ -25,7 +25,7 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, n), 'libsaga_hip.so does not export %s' % n
         assert n in _lib.PROTOTYPES, '%s is declared in the header but not bound in saga_amd/_lib.py' % n
     assert set(_lib.PROTOTYPES) == set(names)
-    assert lib.saga_version() >= 100
+    assert lib.saga_version() >= 300
 
 
 def test_argument_errors_have_messages():
@@ -112,3 +112,24 @@ def test_fit_step_cfg_layout_matches_header():
     names = [n.strip() for decl in body.split(';') if decl.strip() for n in decl.strip().split(None, 1)[1].split(',')]
     assert names == [f[0] for f in _lib.FitStepCfg._fields_]
     assert ctypes.sizeof(_lib.FitStepCfg) == 4 * len(names)
+
+
+def test_release_build_and_quarantined_experiment_switches():
+    """The timing experiments left in the kernel sources (-DGEMM_EXP_*, -DDS_EXP_*, -DGL_EXP_*, -DGL_PHASE_TIMING; several give
+    wrong results by design) compile only together with -DSAGA_EXPERIMENT_BUILD, which makes saga_version() negative -- and
+    _lib.load() refuses such a library.  The tree's library is a release build and exports none of the debug entry points."""
+    from saga_amd import _lib
+    lib = _lib.load()
+    assert lib.saga_version() >= 300
+    for sym in ('saga_debug_gemm_trace', 'saga_debug_read_phases'):
+        assert not hasattr(lib, sym), sym
+    csrc = os.path.join(ROOT, 'saga_amd', 'csrc')
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith(('.hip', '.h')):
+            continue
+        for n, line in enumerate(open(os.path.join(csrc, f)), 1):
+            m = re.match(r'\s*#\s*(ifdef|ifndef|if|elif)\b(.*)', line)
+            if m and re.search(r'\b(GEMM_EXP|DS_EXP|GL_EXP)_\w+|\bGL_PHASE_TIMING\b', m.group(2)):
+                assert 'SAGA_EXPERIMENT_BUILD' in m.group(2), '%s:%d: experiment switch outside SAGA_EXPERIMENT_BUILD: %s' % (f, n, line.strip())
+    mk = open(os.path.join(csrc, 'Makefile')).read()
+    assert 'SAGA_EXPERIMENT_BUILD' not in mk and '_EXP_' not in mk
