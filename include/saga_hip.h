@@ -372,7 +372,8 @@ void saga_decoder_destroy(saga_decoder_t* d);
  * smplx): packed variable rows [B,SAGA_VAR_STRIDE] -> full_pose [B,165] (pose mean added), shape [B,n_shape] (betas, then
  * zeros), transl [B,3]; and the reverse map of the gradients -> grad_vars [B,SAGA_VAR_STRIDE] (g_shape / g_transl may be NULL).
  *   ws: saga_params_workspace_floats(d, B) floats, the SAME buffer for the forward and the backward of one evaluation (it
- *       carries the decoder activations and the 6D->aa Jacobians); the backward may run once per forward. */
+ *       carries the decoder activations and the 6D->aa Jacobians, which the backward reads and leaves intact: it may run any
+ *       number of times per forward, e.g. backward(retain_graph=True) as the reference calls it every iteration). */
 size_t saga_params_workspace_floats(const saga_decoder_t* d, int B);
 int saga_params_fwd(const saga_decoder_t* d, const float* vars, float* full_pose, float* shape, float* transl, int n_shape,
                     float* ws, int B, void* stream);

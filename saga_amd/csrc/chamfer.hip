@@ -365,9 +365,13 @@ __global__ __launch_bounds__(NG_THREADS) void p2p_grad_gather_kernel(const float
 // The same backward for small target clouds (Pa <= P2P_FX_MAX: every call SAGA makes -- 143 markers / 778 hand vertices against
 // 2,048 object points), O(Pa + Pb) per batch element instead of the gather's O(Pa Pb) compares: one block per batch element
 // scatter-adds the other cloud's terms into 64-bit FIXED-POINT accumulators in LDS.  Integer adds are associative, so the result
-// does not depend on the order the LDS atomics land in (bit-reproducible, batch-independent), and it is the exactly rounded sum:
-// the grid is 2^-k with k chosen per batch element from the largest term M so that M Pb 2^k < 2^62 -- every term is on the grid to
-// within 2^-49 M, far below float32 rounding.  (Float atomics, the CUDA reference's way, make the sum order-dependent.)
+// does not depend on the order the LDS atomics land in (bit-reproducible, batch-independent).  The grid is 2^-k with k chosen per
+// batch element from the largest term M so that M Pb 2^k < 2^62: every term is quantised to within 2^-(62 - lp) M (lp = ceil
+// log2 Pb; 2^-51 M for 2,048 points), so a target's sum carries an ABSOLUTE error of at most (its number of terms) x that --
+// far below float32 rounding of M, but a target whose incoming terms are all much smaller than the batch element's largest term
+// M loses relative precision accordingly (below 2^-27 M nothing is left of float32's 24 bits).  A NaN / Inf term sets a flag for
+// its target, whose row is written as NaN -- what torch's scatter-add gives.  (Float atomics, the CUDA reference's way, make the
+// sum order-dependent.)
 #define P2P_FX_MAX 2048
 #define P2P_FX_THREADS 256
 __global__ __launch_bounds__(P2P_FX_THREADS) void p2p_grad_fixed_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -379,11 +383,13 @@ __global__ __launch_bounds__(P2P_FX_THREADS) void p2p_grad_fixed_kernel(const fl
 #pragma clang fp contract(off)
     __shared__ unsigned long long acc[P2P_FX_MAX * 3];
     __shared__ float smax[P2P_FX_THREADS / 64];
+    __shared__ unsigned int sbad[P2P_FX_MAX / 32];              // bit p: a non-finite term landed on target p
     const int n = blockIdx.x, tid = threadIdx.x;
     const float* an = a + (size_t)n * Pa * 3;
     const float* bn = b + (size_t)n * Pb * 3;
     auto sgn = [](float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); };
     for (int i = tid; i < Pa * 3; i += P2P_FX_THREADS) acc[i] = 0ull;
+    for (int i = tid; i < P2P_FX_MAX / 32; i += P2P_FX_THREADS) sbad[i] = 0u;
     // the term point q of b sends to its neighbour in a (evaluated twice: once for the scale, once to add -- cheaper than storing it)
     auto term = [&](int q, float& tx, float& ty, float& tz, int& p) {
         const size_t qi = (size_t)n * Pb + q;
@@ -422,8 +428,13 @@ __global__ __launch_bounds__(P2P_FX_THREADS) void p2p_grad_fixed_kernel(const fl
         for (int q = tid; q < Pb; q += P2P_FX_THREADS) {
             float tx, ty, tz; int p;
             term(q, tx, ty, tz, p);
-            // a NaN / Inf term becomes the largest magnitude of the grid: visible in the result, never undefined behaviour
-            auto fx = [&](float v) { const double s = (double)v * scale; return (s == s && fabs(s) < 4.0e18) ? __double2ll_rn(s) : (long long)4.0e18; };
+            // a NaN / Inf term adds nothing and flags its target (the row is written as NaN below): never undefined behaviour,
+            // never a finite wrong number
+            if (!(fabsf(tx) <= 3.0e38f && fabsf(ty) <= 3.0e38f && fabsf(tz) <= 3.0e38f)) {
+                atomicOr(&sbad[p >> 5], 1u << (p & 31));
+                continue;
+            }
+            auto fx = [&](float v) { return __double2ll_rn((double)v * scale); };       // |v| <= M: inside the grid
             atomicAdd(&acc[p * 3], (unsigned long long)fx(tx));
             atomicAdd(&acc[p * 3 + 1], (unsigned long long)fx(ty));
             atomicAdd(&acc[p * 3 + 2], (unsigned long long)fx(tz));
@@ -446,6 +457,7 @@ __global__ __launch_bounds__(P2P_FX_THREADS) void p2p_grad_fixed_kernel(const fl
             sy -= (double)(long long)acc[p * 3 + 1] * inv_scale;
             sz -= (double)(long long)acc[p * 3 + 2] * inv_scale;
         }
+        if (scatter && ((sbad[p >> 5] >> (p & 31)) & 1u)) { sx = NAN; sy = NAN; sz = NAN; }
         float* o = g_a + i * 3;
         o[0] = (float)sx; o[1] = (float)sy; o[2] = (float)sz;
     }

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(PK_THREADS) void params_fwd_kernel(const float* __r
 
 struct LossCfg { int stage, only_rec, prior, custom; float w_rec, w_foot, reg_vpose, reg_hand, reg_eye, reg_shape; };
 // gradient coefficients of the regularisers, d/dx of w * mean(x^2) = (2 w / n) x  (0: the term is off in this stage)
-struct RegCfg { float c_vpose, c_hand, c_eye; };
+struct RegCfg { float c_vpose, c_hand, c_eye, c_shape; };     // c_shape: custom_weights only (reg_shape * mean(betas^2))
 
 // weighted sum of fittingop.py:215-223 (same order of additions) + the gradient of it w.r.t. the eight fused terms
 // Also the workspace's layout check: when the last saga_fit_step on this workspace carved it differently (another B, O,
@@ -341,7 +341,9 @@ __global__ __launch_bounds__(PK_THREADS) void params_bwd_kernel(const float* __r
         g[SAGA_VAR_EYE + k] = acc;
     } else if (tid >= 86 && tid < 96) {
         const int k = tid - 86;
-        g[SAGA_VAR_BETAS + k] = k < S ? g_shape[(size_t)b * S + k] : 0.f;
+        float acc = k < S ? g_shape[(size_t)b * S + k] : 0.f;
+        if (reg.c_shape != 0.f) acc += reg.c_shape * v[SAGA_VAR_BETAS + k];
+        g[SAGA_VAR_BETAS + k] = acc;
     } else if (tid >= 96 && tid < 99) {
         g[SAGA_VAR_TRANSL + (tid - 96)] = g_transl ? g_transl[(size_t)b * 3 + (tid - 96)] : 0.f;
     } else if (tid >= 126) {
@@ -435,7 +437,7 @@ extern "C" int saga_fit_decode(const saga_decoder_t* d, const float* vars, float
 }
 
 // ---- the parameter maps as a stand-alone operator (autograd callers: GraspMotion-Opt stage 2) --------------------------------
-struct ParamsWs { float *h1, *h2, *x6, *jac, *g_x6, *g_h, *g_z; size_t total; };
+struct ParamsWs { float *h1, *h2, *x6, *jac, *g_x6, *g_h, *g_h1, *g_z; size_t total; };
 static ParamsWs params_ws_carve(float* base, int hidden, int B) {
     ParamsWs w;
     size_t off = 0;
@@ -443,6 +445,7 @@ static ParamsWs params_ws_carve(float* base, int hidden, int B) {
     const size_t b = (size_t)B;
     w.h1 = take(b * hidden); w.h2 = take(b * hidden); w.x6 = take(b * X6_LD); w.jac = take(b * (NB_MAX + 1) * 18);
     w.g_x6 = take(b * X6_LD); w.g_h = take(b * hidden); w.g_z = take(b * 128);
+    w.g_h1 = take(b * hidden);      // (last: the backward leaves the forward's activations h1 / h2 intact, so it can run again)
     w.total = off;
     return w;
 }
@@ -492,13 +495,13 @@ extern "C" int saga_params_bwd(const saga_decoder_t* d, const float* vars, const
     ParamsWs p = params_ws_carve(ws, d->hidden, B);     // h1 / h2 / jac: what saga_params_fwd left there for these vars
     Prof prof(SAGA_PROF_PARAMS_BWD, stream);
     params_bwd_kernel<<<B, PK_THREADS, 0, st>>>(vars, p.jac, d->hand_comp, g_full_pose, g_shape, g_transl, grad_vars, p.g_x6,
-                                                g_shape ? n_shape : 0, d->n_pca, RegCfg{0.f, 0.f, 0.f});
+                                                g_shape ? n_shape : 0, d->n_pca, RegCfg{0.f, 0.f, 0.f, 0.f});
     SAGA_LAUNCH_CHECK();
     int rc;
     if ((rc = saga_launch_gemm_nt(3, p.g_x6, X6_LD, d->w3t, X6_LD, p.g_h, d->hidden, nullptr, p.h2, B, d->hidden, X6_LD, st))) return rc;
-    if ((rc = saga_launch_gemm_nt(3, p.g_h, d->hidden, d->w2t, d->hidden, p.h2, d->hidden, nullptr, p.h1, B, d->hidden, d->hidden, st)))
+    if ((rc = saga_launch_gemm_nt(3, p.g_h, d->hidden, d->w2t, d->hidden, p.g_h1, d->hidden, nullptr, p.h1, B, d->hidden, d->hidden, st)))
         return rc;
-    if ((rc = saga_launch_gemm_nt(0, p.h2, d->hidden, d->w1t, d->hidden, p.g_z, 128, nullptr, nullptr, B, 128, d->hidden, st))) return rc;
+    if ((rc = saga_launch_gemm_nt(0, p.g_h1, d->hidden, d->w1t, d->hidden, p.g_z, 128, nullptr, nullptr, B, 128, d->hidden, st))) return rc;
     const int n = B * VS;
     params_grad_finish_kernel<<<(n + 255) / 256, 256, 0, st>>>(p.g_z, grad_vars, B);
     SAGA_LAUNCH_CHECK();
@@ -633,8 +636,9 @@ static int fit_step_impl(const saga_model_t* m, const saga_model_t* mb, const sa
     }
     // regulariser gradients: fittingop.py:177-181,215-223 (vpose from stage 1 on, hand and eye in stage 2), or the caller's weights
     RegCfg reg{cfg->stage > 0 ? 2.f * 0.0001f / 32.f : 0.f, cfg->stage > 1 ? 2.f * 0.0005f / 48.f : 0.f,
-               cfg->stage > 1 ? 2.f * 0.0001f / 6.f : 0.f};
-    if (cfg->custom_weights) reg = RegCfg{2.f * cfg->reg_vpose / 32.f, 2.f * cfg->reg_hand / 48.f, 2.f * cfg->reg_eye / 6.f};
+               cfg->stage > 1 ? 2.f * 0.0001f / 6.f : 0.f, 0.f};
+    if (cfg->custom_weights)
+        reg = RegCfg{2.f * cfg->reg_vpose / 32.f, 2.f * cfg->reg_hand / 48.f, 2.f * cfg->reg_eye / 6.f, 2.f * cfg->reg_shape / 10.f};
     {
         Prof p(SAGA_PROF_PARAMS_BWD, stream);
         params_bwd_kernel<<<B, PK_THREADS, 0, st>>>(vars, w.jac, d->hand_comp, w.g_pose, w.g_shape, w.g_transl, w.grad, w.g_x6, m->S,

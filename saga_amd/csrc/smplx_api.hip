@@ -26,7 +26,7 @@ int saga_launch_skin_bwd(const saga_model* m, const float* A, const float* g_ver
 #include <vector>
 struct ProfPair { hipEvent_t a, b; int id; };
 static int g_prof_on = 0;       // 0 off, 1 every kernel, 2 only the blend GEMM launches (the roofline kernel)
-static int g_prof_suspend = 0;  // set for the duration of saga_smplx_bwd_noalloc: event creation allocates
+static thread_local int g_prof_suspend = 0;  // set for the duration of saga_smplx_bwd_noalloc ON THE CALLING THREAD: event creation allocates
 static std::vector<ProfPair> g_prof_pairs;
 static std::vector<ProfPair> g_prof_pool;
 

@@ -2,7 +2,8 @@
 
 The reference has no multi-process mode (serial candidate loop, ``opt_grasppose.py:211-222``); here the candidate axis is
 sharded over ranks and every rank is its own process with its own HIP context.  ``launch_ranks`` starts the ranks as fresh
-children (``subprocess``: nothing of the parent's state is inherited, and the parent never touches a GPU) with the
+children (``subprocess``: nothing of the parent's state is inherited; the parent itself makes no HIP call -- it counts the
+GPUs through a short-lived child, ``visible_gpus``) with the
 ``torch.distributed`` environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) -- the same
 variables ``python -m torch.distributed.run`` sets, so a script runs unchanged under either launcher.
 """
@@ -35,9 +36,14 @@ def rank_argv(script_argv, executable=None):
 
 
 def visible_gpus():
-    """Number of visible GPUs WITHOUT initialising one in this process (``device_count`` does not, ``is_available`` does)."""
-    import torch
-    return torch.cuda.device_count()
+    """Number of visible GPUs, counted by a short-lived child process: on ROCm builds of torch ``torch.cuda.device_count()`` ends in
+    ``hipGetDeviceCount``, which brings up the HIP / HSA runtime in the process that calls it -- the launcher would then sit beside
+    its N ranks with an initialised runtime for the whole job.  The child exits before the ranks start."""
+    out = subprocess.run([sys.executable, '-c', 'import torch; print(torch.cuda.device_count())'], capture_output=True, text=True,
+                         timeout=600)
+    if out.returncode != 0:
+        raise RuntimeError('could not count the visible GPUs: %s' % out.stderr.strip()[-500:])
+    return int(out.stdout.strip().splitlines()[-1])
 
 
 def launch_ranks(n, script_argv, check_devices=True, timeout=None, env=None):

@@ -310,6 +310,43 @@ def test_p2p_signed_operator_against_oracle_with_vectors_and_both_gradients():
         point2point_signed(x.cuda(), y.cuda(), directions='neither')
 
 
+def test_p2p_backward_non_finite_upstream_terms_poison_their_target_only():
+    """non-finite upstream gradients.  Three (or more) NaN / Inf terms that land on ONE target used to wrap the 64-bit
+    fixed-point accumulator into a finite garbage gradient; now the target's row is NaN (what torch's scatter-add gives) and every
+    other row is what it is without the poisoned terms."""
+    from saga_amd import _lib
+    g = torch.Generator().manual_seed(2)
+    N, P1, P2 = 2, 50, 400
+    x = (torch.randn(N, P1, 3, generator=g) * 0.1).cuda()
+    y = (torch.randn(N, P2, 3, generator=g) * 0.1).cuda()
+    f32, i32 = dict(device='cuda', dtype=torch.float32), dict(device='cuda', dtype=torch.int32)
+    y2x, x2y = torch.empty(N, P2, **f32), torch.empty(N, P1, **f32)
+    yidx, xidx = torch.empty(N, P2, **i32), torch.empty(N, P1, **i32)
+    P = _lib.ptr
+    _lib.call('saga_p2p_signed_fwd', x.device, P(x), P(y), None, None, P(y2x), P(x2y), P(yidx), P(xidx), None, None, N, P1, P2)
+    g_y2x = torch.randn(N, P2, generator=g).cuda()
+    target = int(torch.bincount(yidx[0].long()).argmax())           # the x point most y points of batch element 0 send to
+    senders = torch.nonzero(yidx[0] == target).flatten()
+    assert senders.numel() >= 4
+    clean = g_y2x.clone()
+    clean[0, senders[:4]] = 0.0
+    bad = g_y2x.clone()
+    bad[0, senders[0]], bad[0, senders[1]], bad[0, senders[2]], bad[0, senders[3]] = float('nan'), float('inf'), float('inf'), float('-inf')
+
+    def bwd(gy):
+        gx = torch.empty(N, P1, 3, **f32)
+        _lib.call('saga_p2p_signed_bwd', x.device, P(x), P(y), P(yidx), P(xidx), P(y2x), P(x2y), P(gy), None, None, None, P(gx), None,
+                  N, P1, P2)
+        return gx
+
+    gx_clean, gx_bad = bwd(clean), bwd(bad)
+    assert torch.isnan(gx_bad[0, target]).all()
+    keep = torch.ones(N, P1, dtype=torch.bool, device='cuda')
+    keep[0, target] = False
+    assert torch.isfinite(gx_bad[keep]).all()
+    np.testing.assert_allclose(gx_bad[keep].cpu().numpy(), gx_clean[keep].cpu().numpy(), rtol=1e-6, atol=1e-9)
+
+
 def test_point2point_signed_value_error():
     from saga_amd.geometry import point2point_signed
     with pytest.raises(ValueError):

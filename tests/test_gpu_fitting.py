@@ -569,6 +569,19 @@ def test_custom_weights_objective_through_the_c_abi(body_model_dir):
         c = slice(*sl[k])
         np.testing.assert_allclose((op.vars[:, c] - before[:, c]).cpu().numpy(), (-lr * torch.sign(before[:, c])).cpu().numpy(),
                                    rtol=1e-4, atol=1e-9, err_msg=k)
+    # with the betas group in the update mask the gradient of reg_shape * mean(betas^2) reaches betas too
+    op.vars.copy_(before); m.zero_(); v.zero_()
+    _lib.call(*args(_lib.FitStepCfg(0, 0, 0, mask | G['betas'], 1, lr, 0.9, 0.999, 1e-8, 1, 1, *dict(w, reg_shape=1e6).values())))
+    c = slice(*sl['betas'])
+    np.testing.assert_allclose((op.vars[:, c] - before[:, c]).cpu().numpy(), (-lr * torch.sign(before[:, c])).cpu().numpy(),
+                               rtol=1e-4, atol=1e-9, err_msg='betas')
+    grad = op.workspace_view('grad', 2048, (B, _lib.VAR_STRIDE))
+    op.vars.copy_(before); m.zero_(); v.zero_()
+    _lib.call(*args(_lib.FitStepCfg(0, 0, 0, mask | G['betas'], 1, lr, 0.9, 0.999, 1e-8, 1, 1, *dict(w, reg_shape=0.0).values())))
+    g0 = grad[:, c].clone()
+    op.vars.copy_(before); m.zero_(); v.zero_()
+    _lib.call(*args(_lib.FitStepCfg(0, 0, 0, mask | G['betas'], 1, lr, 0.9, 0.999, 1e-8, 1, 1, *dict(w, reg_shape=0.7).values())))
+    np.testing.assert_allclose((grad[:, c] - g0).cpu().numpy(), (2 * 0.7 / 10 * before[:, c]).cpu().numpy(), rtol=1e-3, atol=1e-7)
     for bad in (_lib.FitStepCfg(1, 0, 0, mask, 2, lr, 0.9, 0.999, 1e-8, 1, 1, *w.values()),
                 _lib.FitStepCfg(0, 0, 0, mask, 2, lr, 0.9, 0.999, 1e-8, 0, 1, *w.values())):
         with pytest.raises(RuntimeError, match='custom_weights'):

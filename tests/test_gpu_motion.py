@@ -406,9 +406,16 @@ def test_param_maps_operator_matches_torch_maps(body_model_dir):
     w_pose, w_tr = torch.randn(B, 165, generator=g).cuda(), torch.randn(B, 3, generator=g).cuda()
     packed = torch.cat([other, other.new_zeros(B, 6), betas, transl, rot6, other.new_zeros(B, _lib.VAR_STRIDE - 105)], dim=1)
     full_pose, shape, tr = param_maps(packed, dec, 20)
-    ((full_pose * w_pose).sum() + (tr * w_tr).sum()).backward()
+    objective = (full_pose * w_pose).sum() + (tr * w_tr).sum()
+    objective.backward(retain_graph=True)       # the form the reference calls every iteration
     got = [t.grad.clone() for t in (other, transl, rot6)]
     for t in (other, transl, rot6):
+        t.grad = None
+    # a second backward through the same forward (retain_graph, or two losses differentiated separately) used to
+    # read decoder activations the first one had overwritten -- the backward now leaves the saved workspace intact
+    objective.backward()
+    for a, t in zip(got, (other, transl, rot6)):
+        assert torch.equal(a, t.grad), 'the second backward through param_maps differs from the first'
         t.grad = None
     p = convert_to_3D_rot(torch.cat([transl, rot6, betas, other], dim=-1))
     body_pose = vp.decode(p[:, 16:48], output_type='aa').view(B, -1)

@@ -89,3 +89,43 @@ def test_noalloc_rejects_sizes_beyond_its_scratch(body_model_dir):
     with torch.cuda.device(0):
         assert lib.saga_smplx_bwd_noalloc(None, *args[1:], 2, None) == -1
         assert lib.saga_smplx_bwd_noalloc(*args, 0, None) == 0           # empty batch: nothing to do
+
+
+def test_noalloc_backward_under_graph_capture(body_model_dir):
+    """The property the entry point exists for: it can be CAPTURED.  A HIP-graph capture (torch.cuda.graph, global
+    capture mode) fails on any hipMalloc / hipFree / synchronising call inside it; saga_smplx_bwd_noalloc is captured once, then
+    replayed twice on different upstream gradients, and each replay equals saga_smplx_bwd with caller workspaces bit for bit."""
+    from saga_amd import _lib
+    dev = torch.device('cuda', 0)
+    B = 16
+    bm = make_hip_model(body_model_dir, B)
+    h, t = _forward(bm, B, 21)
+    g = torch.Generator().manual_seed(8)
+    f32 = dict(device=dev, dtype=torch.float32)
+    gv = torch.zeros(B, bm.num_verts, 3, **f32)                   # static input / output buffers of the graph
+    gj = torch.zeros(B, bm.num_joints_out, 3, **f32)
+    outs = [torch.zeros(B, n, **f32) for n in (bm.num_shape, 165, 3)]
+    P = _lib.ptr
+
+    def call():
+        _lib.call('saga_smplx_bwd_noalloc', dev, h, P(gv), P(gj), P(t['full_pose']), P(t['rot']), P(t['jrest']), P(t['chain']), P(t['A']),
+                  P(t['v_posed']), P(outs[0]), P(outs[1]), P(outs[2]), B)
+
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        call()                                                    # warm-up off the capture (lazy per-device set-up)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call()
+    for seed in (1, 2):
+        gv.copy_(torch.randn(gv.shape, generator=g).cuda())
+        gj.copy_(torch.randn(gj.shape, generator=g).cuda())
+        for o in outs:
+            o.fill_(float('nan'))
+        graph.replay()
+        torch.cuda.synchronize()
+        want = _backward(h, t, gv, gj, B, bm, noalloc=False)
+        for a, b, name in zip(outs, want, ('g_shape', 'g_full_pose', 'g_transl')):
+            assert torch.isfinite(b).all() and torch.equal(a, b), (seed, name)
