@@ -24,30 +24,11 @@ a = ap.parse_args()
 S, T, start_t = a.sequences, a.frames, 30
 tmp = tempfile.TemporaryDirectory()
 write_body_model(tmp.name, gender='male', seed=7, mesh_faces=a.mesh_faces, local_weights=a.mesh_faces)
-idx = load_grasp_indices()
-g = torch.Generator().manual_seed(0)
-op = FittingOP(dict(T=T, n_seq=S, start_t=start_t, gender='male', device='cuda', smplx_beta=0.5 * torch.randn(S, 10, generator=g).numpy(),
-                    num_iter=[0, 1], markers_ids=idx['markers_f0_p5'], markers_ids_143=idx['markers_143'], body_model_path=tmp.name,
-                    indices=idx, sparse_backward=not a.dense_backward, reduced_forward=not a.full_forward))
-lam = torch.linspace(0, 1, T)[None, :, None]
-transl = torch.tensor([0.0, 0.4, 1.0]) + 0.3 * lam * torch.randn(S, 1, 3, generator=g)
-rot6 = convert_to_6D_all(torch.tensor([[0.0, 1.6, 3.14]]))[None].expand(S, T, 6).contiguous()
-other = 0.1 * torch.randn(S, 1, 80, generator=g) + 0.1 * lam * torch.randn(S, 1, 80, generator=g)
-op.init_param_T(transl, rot6, other, np.repeat(np.asarray(op.shape_t.cpu())[:, None], T, axis=1))
-with torch.no_grad():     # targets: the start motion's own markers, perturbed; the object next to the last frame's right hand
-    from saga_amd.motion_fitting import convert_to_3D_rot, gen_body_mesh_v1
-    p = convert_to_3D_rot(torch.cat([op.transl_opt_T, op.rot_6d_opt_T, op.shape_T, op.other_params_opt_T], -1).reshape(S * T, -1))
-    v = gen_body_mesh_v1(p, op.smplx_model_batch, op.vposer_model)[0].reshape(S, T, -1, 3)
-    markers_rec = v[:, :, op.markers_ids] + 0.01 * torch.randn(S, T, 79, 3, generator=g).cuda()
-    markers_end = markers_rec[:, -1].clone()
-    centre = v[:, -1, torch.from_numpy(idx['rhand']).cuda()].mean(1)
-    del v, p
-vo, no, _, _ = make_object_cloud(S, seed=3)
-vo = torch.from_numpy(vo).float().cuda()
-vo = (vo - vo.mean(1, keepdim=True) + centre[:, None])[:, None].expand(S, T - start_t, -1, 3).contiguous()
-no = torch.from_numpy(no).float().cuda()[:, None].expand(S, T - start_t, -1, 3).contiguous()
-lbl = (torch.rand(S, T, 4, generator=g) > 0.4).float()
-c_obj, c_mk = torch.rand(S, 2048, generator=g), torch.rand(S, 143, generator=g)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from workloads import motion_stage2
+op, run_n = motion_stage2(tmp.name, S, T, start_t, sparse_backward=not a.dense_backward, reduced_forward=not a.full_forward)
+dd = op.bench_data
+idx, markers_rec, markers_end, lbl, c_obj, c_mk, no, vo = (dd[k] for k in ('idx', 'markers_rec', 'markers_end', 'lbl', 'c_obj', 'c_mk', 'no', 'vo'))
 if a.whole_fit:
     op.num_iter = [100, 300]
     op.init_param_t()
