@@ -164,6 +164,16 @@ int saga_cont6d_to_aa_bwd(const float* jac, const float* g_aa, float* g_x6, int 
  * ------------------------------------------------------------------------------------------ */
 int saga_chamfer_fwd(const float* x, const float* y, float* dist1, float* dist2,
                      int32_t* idx1, int32_t* idx2, int N, int P1, int P2, void* stream);
+/* The same search for LARGE clouds with a caller-provided workspace (BASELINE config 5: 10,475 body vertices against 100,000 scene
+ * points; reference call shape utils/train_helper.py:57, WholeGraspPose/trainer.py:280-281).  A direction whose database cloud has
+ * >= 4,096 points is searched with spatial pruning -- both clouds counting-sorted into a 32^3 Morton grid, boxes per 32 / 2,048
+ * sorted points, database tiles visited nearest first, (query tile, point group) pairs skipped by box-to-box bounds -- and returns
+ * EXACTLY what saga_chamfer_fwd returns (same squared distances, same original indices, lowest index on ties).
+ *   saga_chamfer_workspace_bytes: bytes of device workspace (16-byte aligned, contents undefined) the call needs for these sizes;
+ *   0 = no direction is large enough, saga_chamfer_fwd_ws then IS saga_chamfer_fwd (ws may be NULL). */
+size_t saga_chamfer_workspace_bytes(int N, int P1, int P2);
+int saga_chamfer_fwd_ws(const float* x, const float* y, float* dist1, float* dist2, int32_t* idx1, int32_t* idx2,
+                        int N, int P1, int P2, void* ws, size_t ws_bytes, void* stream);
 /* the extension's own backward (NmDistanceGrad): the gradients are ADDED to g_x, g_y (zero-initialise them for the plain
  * gradient); never driven by SAGA itself but part of the package's API.  Deterministic: a gather in
  * a fixed order per point instead of the extension's float atomics -- bit-reproducible, batch-independent. */

@@ -120,6 +120,9 @@ PROTOTYPES = {
     'saga_cont6d_to_aa_bwd': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, ctypes.c_int, c_stream]),
     'saga_chamfer_fwd': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_int_p, c_int_p,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    'saga_chamfer_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'saga_chamfer_fwd_ws': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_int_p, c_int_p,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, c_stream]),
     'saga_chamfer_bwd': (ctypes.c_int, [c_float_p, c_float_p, c_int_p, c_int_p, c_float_p, c_float_p,
                                         c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
     'saga_p2p_signed_fwd': (ctypes.c_int, [c_float_p] * 6 + [c_int_p, c_int_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,

@@ -3,6 +3,20 @@ import torch
 from .. import _lib
 
 
+def _nn_search(x, y, dist1, dist2, idx1, idx2):
+    """saga_chamfer_fwd, or -- when a cloud is large enough for the pruned search (saga_chamfer_workspace_bytes > 0: >= 4,096
+    database points) -- saga_chamfer_fwd_ws with a workspace allocated here.  Same outputs either way, bit for bit."""
+    N, P1, P2 = x.shape[0], x.shape[1], y.shape[1]
+    lib = _lib.load()
+    nbytes = lib.saga_chamfer_workspace_bytes(N, P1, P2) if N > 0 and P1 > 0 and P2 > 0 else 0
+    P = _lib.ptr
+    if nbytes:
+        ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+        _lib.call('saga_chamfer_fwd_ws', x.device, P(x), P(y), P(dist1), P(dist2), P(idx1), P(idx2), N, P1, P2, P(ws), nbytes)
+    else:
+        _lib.call('saga_chamfer_fwd', x.device, P(x), P(y), P(dist1), P(dist2), P(idx1), P(idx2), N, P1, P2)
+
+
 class _ChamferFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y):
@@ -19,9 +33,7 @@ class _ChamferFn(torch.autograd.Function):
         dist2 = torch.empty(N, P2, device=dev, dtype=torch.float32)
         idx1 = torch.empty(N, P1, device=dev, dtype=torch.int32)
         idx2 = torch.empty(N, P2, device=dev, dtype=torch.int32)
-        lib = _lib.load()
-        _lib.call('saga_chamfer_fwd', x.device, _lib.ptr(x), _lib.ptr(y), _lib.ptr(dist1), _lib.ptr(dist2), _lib.ptr(idx1),
-                                        _lib.ptr(idx2), N, P1, P2)
+        _nn_search(x, y, dist1, dist2, idx1, idx2)
         ctx.save_for_backward(x, y, idx1, idx2)
         ctx.mark_non_differentiable(idx1, idx2)
         ctx.set_materialize_grads(False)
@@ -55,8 +67,7 @@ def chamfer_nn(x, y):
     P2 = y.shape[1]
     idx1 = torch.empty(N, P1, device=x.device, dtype=torch.int32)
     idx2 = torch.empty(N, P2, device=x.device, dtype=torch.int32)
-    lib = _lib.load()
-    _lib.call('saga_chamfer_fwd', x.device, _lib.ptr(x), _lib.ptr(y), None, None, _lib.ptr(idx1), _lib.ptr(idx2), N, P1, P2)
+    _nn_search(x, y, None, None, idx1, idx2)
     return idx1, idx2
 
 

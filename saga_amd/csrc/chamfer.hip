@@ -11,6 +11,7 @@
 #include "saga_common.h"
 #include "nn_scan.h"
 #include "nn_fast.h"
+#include "nn_prune.h"
 
 void* saga_prof_begin(int id, void* stream);
 void saga_prof_end(void* scope);
@@ -158,6 +159,90 @@ extern "C" int saga_chamfer_fwd(const float* x, const float* y, float* dist1, fl
     if (!rc) rc = launch_scan(y, x, dist2, idx2, N, P2, P1, (hipStream_t)stream);
     saga_prof_end(prof);
     return rc;
+}
+
+// ---- large clouds: the pruned search of nn_prune.h ------------------------------------------------------------------------
+// A direction (queries -> database) is pruned when the database has at least NNP_MIN_DB points (below that the brute-force scan's
+// two or three tiles cost less than sorting) and at most NNP_MAX_TILES tiles.  SAGA_NN_PRUNE=0 switches it off (cross-check).
+#define NNP_MIN_DB 4096
+static bool nnp_direction(int Pd) {
+    const char* e = getenv("SAGA_NN_PRUNE");
+    if (e && e[0] == '0') return false;
+    const char* f = getenv("SAGA_NN_EXACT_SCAN");
+    if (f && f[0] == '1') return false;
+    return Pd >= NNP_MIN_DB && (Pd + NNP_TILE - 1) / NNP_TILE <= NNP_MAX_TILES;
+}
+struct NnpLayout { size_t sx, sy, gbx, tbx, gby, tby, total; int tx, ty; bool px, py; };      // byte offsets; px: database x is pruned (y -> x)
+static NnpLayout nnp_layout(int N, int P1, int P2) {
+    NnpLayout L;
+    memset(&L, 0, sizeof(L));
+    L.px = nnp_direction(P1); L.py = nnp_direction(P2);
+    if (!L.px && !L.py) return L;
+    L.tx = (P1 + NNP_TILE - 1) / NNP_TILE; L.ty = (P2 + NNP_TILE - 1) / NNP_TILE;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    L.sx = take((size_t)N * P1 * sizeof(float4));
+    L.sy = take((size_t)N * P2 * sizeof(float4));
+    if (L.px) { L.gbx = take((size_t)N * L.tx * NNP_GPT * 6 * sizeof(float)); L.tbx = take((size_t)N * L.tx * 6 * sizeof(float)); }
+    if (L.py) { L.gby = take((size_t)N * L.ty * NNP_GPT * 6 * sizeof(float)); L.tby = take((size_t)N * L.ty * 6 * sizeof(float)); }
+    L.total = off;
+    return L;
+}
+
+extern "C" size_t saga_chamfer_workspace_bytes(int N, int P1, int P2) {
+    if (N <= 0 || P1 <= 0 || P2 <= 0) return 0;
+    return nnp_layout(N, P1, P2).total;
+}
+
+extern "C" int saga_chamfer_fwd_ws(const float* x, const float* y, float* dist1, float* dist2, int32_t* idx1, int32_t* idx2, int N,
+                                   int P1, int P2, void* ws, size_t ws_bytes, void* stream) {
+    SAGA_CHECK_ARG(N >= 0 && P1 >= 0 && P2 >= 0, "saga_chamfer_fwd_ws: negative size");
+    if (N == 0 || (P1 == 0 && P2 == 0)) return 0;
+    SAGA_CHECK_ARG(P1 > 0 && P2 > 0, "saga_chamfer_fwd_ws: empty cloud (P1=%d, P2=%d) has no nearest neighbour", P1, P2);
+    const NnpLayout L = nnp_layout(N, P1, P2);
+    if (L.total == 0 || !ws) return saga_chamfer_fwd(x, y, dist1, dist2, idx1, idx2, N, P1, P2, stream);
+    SAGA_CHECK_ARG(ws_bytes >= L.total, "saga_chamfer_fwd_ws: workspace of %zu bytes, saga_chamfer_workspace_bytes says %zu", ws_bytes, L.total);
+    SAGA_CHECK_ARG(((uintptr_t)ws & 15) == 0, "saga_chamfer_fwd_ws: the workspace must be 16-byte aligned");
+    SAGA_CHECK_ARG(x && y, "saga_chamfer_fwd_ws: null cloud");
+    SAGA_CHECK_ARG(N <= 65535, "saga_chamfer_fwd_ws: batch %d exceeds 65535", N);
+    hipStream_t st = (hipStream_t)stream;
+    {
+        int dev = 0;
+        SAGA_HIP(hipGetDevice(&dev));
+        static bool attr_set[64] = {};
+        if (!attr_set[dev & 63]) {
+            SAGA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nnp_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         NNP_CELLS * (int)sizeof(unsigned int)));
+            attr_set[dev & 63] = true;
+        }
+    }
+    char* base = (char*)ws;
+    float4* sx = (float4*)(base + L.sx);
+    float4* sy = (float4*)(base + L.sy);
+    void* prof = saga_prof_begin(SAGA_PROF_CHAMFER, stream);
+    nnp_sort_kernel<<<N, NNP_SORT_THREADS, NNP_CELLS * sizeof(unsigned int), st>>>(x, sx, P1);
+    nnp_sort_kernel<<<N, NNP_SORT_THREADS, NNP_CELLS * sizeof(unsigned int), st>>>(y, sy, P2);
+    if (L.px) nnp_boxes_kernel<<<dim3((L.tx + 3) / 4, N), 256, 0, st>>>(sx, (float*)(base + L.gbx), (float*)(base + L.tbx), P1, L.tx);
+    if (L.py) nnp_boxes_kernel<<<dim3((L.ty + 3) / 4, N), 256, 0, st>>>(sy, (float*)(base + L.gby), (float*)(base + L.tby), P2, L.ty);
+    int rc = 0;
+    if (dist1 || idx1) {
+        if (L.py)
+            nnp_scan_kernel<<<dim3((P1 + NNP_QPB - 1) / NNP_QPB, N), NNP_THREADS, 0, st>>>(sx, sy, (const float*)(base + L.gby),
+                                                                                         (const float*)(base + L.tby), dist1, idx1, P1, P2, L.ty);
+        else
+            rc = launch_scan(x, y, dist1, idx1, N, P1, P2, st);
+    }
+    if (!rc && (dist2 || idx2)) {
+        if (L.px)
+            nnp_scan_kernel<<<dim3((P2 + NNP_QPB - 1) / NNP_QPB, N), NNP_THREADS, 0, st>>>(sy, sx, (const float*)(base + L.gbx),
+                                                                                         (const float*)(base + L.tbx), dist2, idx2, P2, P1, L.tx);
+        else
+            rc = launch_scan(y, x, dist2, idx2, N, P2, P1, st);
+    }
+    saga_prof_end(prof);
+    if (rc) return rc;
+    SAGA_LAUNCH_CHECK();
+    return 0;
 }
 
 // Backward of the two squared-distance outputs (the extension's NmDistanceGrad): for every point p of a with neighbour

@@ -405,8 +405,11 @@ __device__ __forceinline__ void nnf_scan_mfma(const float* __restrict__ s, int n
 
 // exact evaluation of one chunk for one query (original coordinates o*), index order, strict '<'.  Two points per packed
 // instruction; every packed lane performs the IEEE operation of nn_dist2, so the values are those of the scalar chain.
+// ORIG (nn_prune.h: the tile holds SORTED points): sorig[k] is the original index of tile point k, bi carries original indices and
+// the comparison is lexicographic on (distance, original index) -- the result no longer depends on the order points are visited in.
+template <bool ORIG = false>
 __device__ __forceinline__ void nnf_exact_chunk(const float* __restrict__ s, const NnfFrame f, int ch, int base, float ox, float oy,
-                                                float oz, float& best, int& bi) {
+                                                float oz, float& best, int& bi, const int* __restrict__ sorig = nullptr) {
 #pragma clang fp contract(off)
     const float4* t = reinterpret_cast<const float4*>(s + ch * NNF_CSTRIDE);
     const nn_f2 mh = {-0.5f, -0.5f}, cx = {f.cx, f.cx}, cy = {f.cy, f.cy}, cz = {f.cz, f.cz};
@@ -419,9 +422,15 @@ __device__ __forceinline__ void nnf_exact_chunk(const float* __restrict__ s, con
                     pz = __builtin_elementwise_fma(mh, Z, cz);                          // original coordinates, bit-exact
         const nn_f2 dx = qx - px, dy = qy - py, dz = qz - pz;
         const nn_f2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-        const int k = base + ch * NNF_CH + 2 * g;
-        if (d.x < best) { best = d.x; bi = k; }
-        if (d.y < best) { best = d.y; bi = k + 1; }
+        if (ORIG) {
+            const int2 o = *reinterpret_cast<const int2*>(sorig + ch * NNF_CH + 2 * g);
+            if (d.x < best || (d.x == best && o.x < bi)) { best = d.x; bi = o.x; }
+            if (d.y < best || (d.y == best && o.y < bi)) { best = d.y; bi = o.y; }
+        } else {
+            const int k = base + ch * NNF_CH + 2 * g;
+            if (d.x < best) { best = d.x; bi = k; }
+            if (d.y < best) { best = d.y; bi = k + 1; }
+        }
     }
 }
 
@@ -430,13 +439,13 @@ __device__ __forceinline__ void nnf_exact_chunk(const float* __restrict__ s, con
 // (global index of point 0 of this tile = base; tiles must come in index order).  Every lane of the wave must call it
 // together (the slow path is a wave-wide loop).
 // MFMA_PASS: the chunk minima come from nnf_scan_mfma (its error bound replaces the vector pass's).
-template <int NQ, bool MFMA_PASS = false>
+template <int NQ, bool MFMA_PASS = false, bool ORIG = false>
 __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_chunks, const NnfFrame f, int base,
                                             const float (&qx)[NQ], const float (&qy)[NQ], const float (&qz)[NQ],
                                             const float (&ox)[NQ], const float (&oy)[NQ], const float (&oz)[NQ],
                                             const float (&m1)[NQ], const float (&m2)[NQ], const float (&m3)[NQ],
                                             const int (&c1)[NQ], const int (&c2)[NQ],
-                                            float (&best)[NQ], int (&bi)[NQ]) {
+                                            float (&best)[NQ], int (&bi)[NQ], const int* __restrict__ sorig = nullptr) {
     const int lane = __lane_id();
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -455,8 +464,8 @@ __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_c
             const bool two = c2[i] >= 0 && m2[i] <= thr;
             const int a = two ? min(c1[i], c2[i]) : c1[i];
             const int b = two ? max(c1[i], c2[i]) : c1[i];
-            nnf_exact_chunk(s, f, a, base, ox[i], oy[i], oz[i], best[i], bi[i]);
-            if (b != a) nnf_exact_chunk(s, f, b, base, ox[i], oy[i], oz[i], best[i], bi[i]);
+            nnf_exact_chunk<ORIG>(s, f, a, base, ox[i], oy[i], oz[i], best[i], bi[i], sorig);
+            if (b != a) nnf_exact_chunk<ORIG>(s, f, b, base, ox[i], oy[i], oz[i], best[i], bi[i], sorig);
         }
         // slow path (three or more chunks inside the margin), one query at a time with the whole wave: lane l takes
         // chunks l, l+64, ..., re-evaluates those whose approximate minimum is inside the margin exactly (ascending, strict
@@ -482,7 +491,7 @@ __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_c
                     const float v1 = __builtin_fmaf(sqz, b.y, __builtin_fmaf(sqy, a.w, __builtin_fmaf(sqx, a.y, b.w)));
                     m = __builtin_fminf(__builtin_fminf(m, v0), v1);
                 }
-                if (m <= sthr) nnf_exact_chunk(s, f, c, base, sox, soy, soz, cb, ci);
+                if (m <= sthr) nnf_exact_chunk<ORIG>(s, f, c, base, sox, soy, soz, cb, ci, sorig);
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
@@ -492,7 +501,7 @@ __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_c
                 cb = take ? ob : cb;
                 ci = take ? oi : ci;
             }
-            if (lane == src && cb < best[i]) { best[i] = cb; bi[i] = ci; }
+            if (lane == src && (cb < best[i] || (ORIG && cb == best[i] && ci < bi[i]))) { best[i] = cb; bi[i] = ci; }
         }
     }
 }

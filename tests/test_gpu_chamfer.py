@@ -138,6 +138,85 @@ def test_chamfer_dense_clouds_multi_tile(N, P1, P2):
     _check(x.contiguous(), y.contiguous())
 
 
+def _pruned_cases():
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=g)
+    lat = torch.stack(torch.meshgrid(*[torch.arange(17.)] * 3, indexing='ij'), -1).reshape(1, -1, 3)
+    y6 = r(1, 6000, 3)
+    return {
+        'gauss': (r(3, 5000, 3), r(3, 9000, 3) * 0.5 + 0.3),
+        'body_vs_scene': (r(2, 10475, 3) * torch.tensor([0.3, 0.15, 0.85]) + torch.tensor([0., 0., 0.9]), r(2, 30000, 3) * 0.25 + torch.tensor([0.3, 0.1, 1.0])),
+        'far_apart': (r(2, 4096, 3) + 100.0, r(2, 4097, 3) * 0.01),
+        'duplicates': (r(1, 5000, 3), torch.cat([y6, y6], 1)),                    # every database point twice, 6,000 indices apart
+        'all_identical': (torch.zeros(2, 4100, 3) + 0.5, torch.zeros(2, 4100, 3) + 0.5),
+        'lattice_ties': (lat + 0.5, lat),                                         # every query has eight equidistant neighbours
+        'planar': (torch.cat([r(2, 7000, 2), torch.zeros(2, 7000, 1)], -1), torch.cat([r(2, 20000, 2), torch.zeros(2, 20000, 1) + 0.1], -1)),
+        'few_queries': (r(4, 143, 3), r(4, 50000, 3)),
+        'one_query': (r(1, 1, 3), r(1, 4096, 3)),
+        'ragged': (r(3, 4999, 3) * 3, r(3, 6001, 3)),
+        'two_clusters': (torch.cat([r(2, 4500, 3) * 0.01, r(2, 4500, 3) * 0.01 + 5], 1), torch.cat([r(2, 4500, 3) * 0.01 + 5, r(2, 4500, 3) * 0.01], 1)),
+        'sphere_shell': (r(2, 300, 3) * 0.01, torch.nn.functional.normalize(r(2, 8192, 3), dim=-1)),    # all points ~equidistant from every query
+    }
+
+
+@pytest.mark.parametrize('case', sorted(_pruned_cases()))
+def test_chamfer_pruned_search_equals_exact_scan(case):
+    """Clouds of >= 4,096 points take the pruned search (nn_prune.h: Morton-cell counting sort, box bounds per 32 / 512 sorted
+    points, per-query refinement; ChamferDistance allocates its workspace).  It must return what the sequential exact scan
+    returns -- same squared distances, same ORIGINAL indices, lowest index on ties -- although it visits the points in another
+    order: against the plain exact-scan kernel (SAGA_NN_EXACT_SCAN=1) on every case and against the C oracle where that takes
+    seconds.  Cases: duplicates far apart in index, lattices (8-way ties), coincident clouds, planes, far / tiny clusters, shells."""
+    import os
+    import saga_amd.chamfer_distance as chd
+    from saga_amd import _lib
+    x, y = (t.float().contiguous() for t in _pruned_cases()[case])
+    assert _lib.load().saga_chamfer_workspace_bytes(x.shape[0], x.shape[1], y.shape[1]) > 0, 'the case does not reach the pruned search'
+    got = chd.ChamferDistance(x.cuda(), y.cuda())
+    os.environ['SAGA_NN_EXACT_SCAN'] = '1'
+    try:
+        want = chd.ChamferDistance(x.cuda(), y.cuda())
+    finally:
+        del os.environ['SAGA_NN_EXACT_SCAN']
+    for a, b, name in zip(got, want, ('dist1', 'dist2', 'idx1', 'idx2')):
+        assert_same(a.cpu().numpy(), b.cpu().numpy(), name)
+    if x.shape[0] * x.shape[1] * y.shape[1] <= 150e6:
+        r1, r2, j1, j2 = chamfer_ref.chamfer_distance(x, y)
+        assert_same(got[2].cpu().numpy(), j1.numpy(), 'idx1 vs oracle')
+        assert_same(got[3].cpu().numpy(), j2.numpy(), 'idx2 vs oracle')
+        assert_same(got[0].cpu().numpy(), r1.numpy(), 'dist1 vs oracle')
+
+
+def test_chamfer_workspace_entry_point_through_the_c_abi():
+    """saga_chamfer_fwd_ws: a workspace that is too small is refused with a message; without a workspace (or for small clouds) it
+    is saga_chamfer_fwd; any output may be NULL; the scratch contents do not matter (poisoned workspace, two calls)."""
+    from saga_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    N, P1, P2 = 2, 600, 9000
+    x, y = torch.randn(N, P1, 3, generator=g).cuda(), (torch.randn(N, P2, 3, generator=g) * 0.7).cuda()
+    nb = lib.saga_chamfer_workspace_bytes(N, P1, P2)
+    assert nb > 0 and lib.saga_chamfer_workspace_bytes(N, 600, 2048) == 0 and lib.saga_chamfer_workspace_bytes(0, P1, P2) == 0
+    P = _lib.ptr
+    f32, i32 = dict(device='cuda', dtype=torch.float32), dict(device='cuda', dtype=torch.int32)
+    ref = [torch.empty(N, P1, **f32), torch.empty(N, P2, **f32), torch.empty(N, P1, **i32), torch.empty(N, P2, **i32)]
+    _lib.call('saga_chamfer_fwd', x.device, P(x), P(y), *(P(t) for t in ref), N, P1, P2)
+    for fill in (0x00, 0xff):
+        ws = torch.full((nb,), fill, device='cuda', dtype=torch.uint8)
+        out = [torch.empty_like(t) for t in ref]
+        _lib.call('saga_chamfer_fwd_ws', x.device, P(x), P(y), *(P(t) for t in out), N, P1, P2, P(ws), nb)
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
+    only_idx1 = torch.empty(N, P1, **i32)
+    _lib.call('saga_chamfer_fwd_ws', x.device, P(x), P(y), None, None, P(only_idx1), None, N, P1, P2, P(ws), nb)
+    assert torch.equal(only_idx1, ref[2])
+    with torch.cuda.device(0):
+        rc = lib.saga_chamfer_fwd_ws(P(x), P(y), None, None, P(only_idx1), None, N, P1, P2, P(ws), nb - 1, None)
+    assert rc == -1 and b'workspace' in lib.saga_last_error()
+    no_ws = torch.empty(N, P1, **i32)
+    _lib.call('saga_chamfer_fwd_ws', x.device, P(x), P(y), None, None, P(no_ws), None, N, P1, P2, None, 0)      # brute force
+    assert torch.equal(no_ws, ref[2])
+
+
 def test_chamfer_both_call_forms_and_errors():
     import saga_amd.chamfer_distance as chd
     x = torch.randn(1, 5, 3).cuda()
