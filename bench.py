@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_TFLOPS = 157.3     # MI355X dense FP32 (vector = matrix), /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (same guide; ~6.3 TB/s achievable)
 V, K_ALG = 10475, 506       # algorithmic K of the blend contraction: 20 shape + 486 pose-feature columns (padded to 512)
-PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'round2_pmc_summary.json')
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'current_pmc_summary.json')
 GEMM_ENV_FLAGS = ('SAGA_GEMM_LEPI', 'SAGA_GEMM_XCD')
 
 

@@ -23,5 +23,5 @@ b = os.path.join(src, 'bench_trace.json')
 if os.path.exists(b):
     shutil.copy(b, os.path.join(root, 'profiles', name + '_bench_under_rocprof.json'))
 if '--current' in sys.argv:      # the summary bench.py reads for roofline.traffic
-    json.dump(d, open(os.path.join(root, 'profiles', 'round2_pmc_summary.json'), 'w'), indent=1, sort_keys=True)
+    json.dump(d, open(os.path.join(root, 'profiles', 'current_pmc_summary.json'), 'w'), indent=1, sort_keys=True)
 print('profiles/%s_* written at %s' % (name, d['_meta']['git_head']))
