@@ -464,6 +464,67 @@ int saga_fit_best_update(const float* loss, const float* vars, const float* mark
                          float* best_loss, float* best_vars, float* best_markers, int B, int M, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Whole GraspMotion-Opt stage-2 iteration on the device.  Replaces, for S independent sequences of T frames, one pass of the
+ * loop body of FittingOP.fitting_stage2 (MotionFill/models/fittingop.py:342-414: zero_grad, the objective :356-409 with its
+ * helpers :132-280, loss.backward, optimizer.step) with no host work and no framework kernel between the launches:
+ *   saga_params_fwd, saga_smplx_fwd_selected, saga_pick_sets_fwd, saga_vertex_normals_subset_window (hand, palm markers),
+ *   saga_p2p_signed_fwd x2 (markers -> object :154, object -> hand :157), saga_motion_terms_fwd, the two regularisers and the
+ *   weighted sum (:391-409), the reverse of each, and torch.optim.Adam's update (:344-350; no weight decay) of transl, rot6d,
+ *   the VPoser latent and the hand coefficients.  The learned smoothness prior (:70-130) is not part of it.
+ * The variables of the S*T bodies are packed rows [S*T,SAGA_VAR_STRIDE] (sequence-major; the layout of saga_fit_step: betas
+ * are read, not updated; the eye columns are ignored and must be 0).
+ *   m       the body model the objective is evaluated on: the full mesh, or a vertex-subset model that holds every vertex the
+ *           terms read plus the face ring around the hand / palm-marker vertices (their normals)
+ *   m_grad  saga_model_create_subset over the vertices the terms read (rows of m's mesh; U = its vertex count): the backward
+ *           runs on it
+ *   tables  DEVICE index arrays: the four pick sets out of m_grad's rows -- 0: markers [M] (every frame), 1: the four heel / toe
+ *           groups side by side in contact_lbl's column order (every frame), 2: the contact markers [CM] (frames T-n_tail..),
+ *           3: the right hand [H] (frames T-n_tail..) -- each with pos, inv_ptr, inv_idx, n, t0 (out / g_out are ignored);
+ *           hand_normal_sel [H] / palm_normal_sel [NP]: rows of m's vertices of the right hand (order of set 3) and of the
+ *           last NP contact markers; marker_mask [M] (:360-364)
+ *   problem DEVICE targets: markers_rec [S,T,M,3], markers_end [S,M,3], contact_lbl [S,T,4], contact_object [S,O],
+ *           contact_markers [S,CM], verts_object / normal_object [S,n_tail,O,3]
+ *   cfg     sizes (terms), the nine stage2_weight_loss_* weights (opt_graspmotion.py:470-495), Adam state: adam_step is the
+ *           1-based step count (0: evaluate the objective and its gradient only, no update), lr (0.01, 0.005 after step 150)
+ *   ws      saga_motion_step_workspace_floats floats, contents undefined; after the call it holds every intermediate
+ *           (saga_motion_step_workspace_offset: "vertices", "vertices_sel", "markers", "feet", "contact_markers_tail", "hand_tail",
+ *           "hand_normals", "palm_normals", "h2o_marker", "h2o_marker_vec", "o2h_signed", "idx_m2o" / "idx_o2h" (int32), "terms"
+ *           [S,SAGA_MOTION_NTERMS], "g_terms" [S,7], "g_vertices_sel", "g_full_pose", "g_shape", "g_transl", "full_pose", "shape",
+ *           "transl", "grad" [S*T,SAGA_VAR_STRIDE] = gradient rows, regularisers included; else -1)
+ *   loss [S] out: per-sequence objective (before the update).  terms_out [S,16] out or NULL: total, rec_markers,
+ *           end_markers_fit, skating, hand_smooth, contact, collision, hand_angle, vposer, hand, the four skating counts, 2 pads.
+ * S*T <= 65535.  Bit-reproducible; a sequence's result does not depend on the batch it is in.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    saga_pick_set_t sets[4];
+    const int32_t* hand_normal_sel;
+    const int32_t* palm_normal_sel;
+    const float* marker_mask;
+} saga_motion_tables_t;
+typedef struct {
+    const float* markers_rec;
+    const float* markers_end;
+    const float* contact_lbl;
+    const float* contact_object;
+    const float* contact_markers;
+    const float* verts_object;
+    const float* normal_object;
+} saga_motion_problem_t;
+typedef struct {
+    saga_motion_terms_cfg_t terms;
+    float w_rec_markers, w_end_markers_fit, w_vposer, w_hand, w_skating, w_hand_smooth, w_collision, w_contact, w_hand_angle;
+    int32_t adam_step;
+    float lr, beta1, beta2, eps;
+} saga_motion_step_cfg_t;
+size_t saga_motion_step_workspace_floats(const saga_model_t* m, const saga_model_t* m_grad, const saga_decoder_t* dec,
+                                         const saga_motion_step_cfg_t* cfg);
+long long saga_motion_step_workspace_offset(const saga_model_t* m, const saga_model_t* m_grad, const saga_decoder_t* dec,
+                                            const saga_motion_step_cfg_t* cfg, const char* name);
+int saga_motion_step(const saga_model_t* m, const saga_model_t* m_grad, const saga_decoder_t* dec,
+                     const saga_motion_tables_t* tables, const saga_motion_problem_t* prob, const saga_motion_step_cfg_t* cfg,
+                     float* vars, float* adam_m, float* adam_v, float* ws, float* loss, float* terms_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel timing for bench.py (no counterpart in the reference, whose only timing hook is the
  * disabled `time per sample` log at WholeGraspPose/models/fittingop.py:376,491-492).
  * saga_profile_enable(1): every kernel launch of the entry points above is bracketed by a hipEvent pair on

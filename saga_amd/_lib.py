@@ -64,6 +64,31 @@ class MotionTermsCfg(ctypes.Structure):
 
 
 MOTION_NTERMS = 12
+
+
+class MotionTables(ctypes.Structure):
+    """saga_motion_tables_t"""
+    _fields_ = [('sets', PickSet * 4), ('hand_normal_sel', ctypes.c_void_p), ('palm_normal_sel', ctypes.c_void_p),
+                ('marker_mask', ctypes.c_void_p)]
+
+
+class MotionProblem(ctypes.Structure):
+    """saga_motion_problem_t"""
+    _fields_ = [(k, ctypes.c_void_p) for k in ('markers_rec', 'markers_end', 'contact_lbl', 'contact_object', 'contact_markers',
+                                               'verts_object', 'normal_object')]
+
+
+MOTION_WEIGHTS = ('rec_markers', 'end_markers_fit', 'vposer', 'hand', 'skating', 'hand_smooth', 'collision', 'contact', 'hand_angle')
+MOTION_STEP_TERMS = ('total', 'rec_markers', 'end_markers_fit', 'skating', 'hand_smooth', 'contact', 'collision', 'hand_angle',
+                     'vposer', 'hand')                       # columns 0..9 of saga_motion_step's terms_out [S,16]
+
+
+class MotionStepCfg(ctypes.Structure):
+    """saga_motion_step_cfg_t"""
+    _fields_ = ([('terms', MotionTermsCfg)] + [('w_' + k, ctypes.c_float) for k in MOTION_WEIGHTS] +
+                [('adam_step', ctypes.c_int32), ('lr', ctypes.c_float), ('beta1', ctypes.c_float), ('beta2', ctypes.c_float),
+                 ('eps', ctypes.c_float)])
+
 GRASP_NTERMS = 16
 
 # packed optimiser-variable row (include/saga_hip.h SAGA_VAR_*)
@@ -131,6 +156,11 @@ PROTOTYPES = {
                                            ctypes.c_int, c_stream]),
     'saga_pick_sets_fwd': (ctypes.c_int, [c_float_p, ctypes.POINTER(PickSet), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
     'saga_pick_sets_bwd': (ctypes.c_int, [ctypes.POINTER(PickSet), ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    'saga_motion_step_workspace_floats': (ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(MotionStepCfg)]),
+    'saga_motion_step_workspace_offset': (ctypes.c_longlong, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                              ctypes.POINTER(MotionStepCfg), ctypes.c_char_p]),
+    'saga_motion_step': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(MotionTables),
+                                        ctypes.POINTER(MotionProblem), ctypes.POINTER(MotionStepCfg)] + [c_float_p] * 6 + [c_stream]),
     'saga_params_workspace_floats': (ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_int]),
     'saga_params_fwd': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, c_stream]),
     'saga_params_bwd': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_float_p,

@@ -371,12 +371,12 @@ __global__ void adam_kernel(float* __restrict__ vars, float* __restrict__ m, flo
                             int32_t* __restrict__ hdr, int32_t layout) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * SAGA_VAR_COUNT) return;
-    if (i == 0) hdr[0] = layout;
+    if (i == 0 && hdr) hdr[0] = layout;
     const int b = i / SAGA_VAR_COUNT, col = i % SAGA_VAR_COUNT;
     if (!(var_group(col) & c.mask)) return;
     const size_t o = (size_t)b * VS + col;
     float g;
-    if (col < SAGA_VAR_HAND) {
+    if (col < SAGA_VAR_HAND && g_z) {                  // (g_z NULL: complete gradient rows, saga_adam_rows)
         g = g_z[(size_t)b * 128 + col];
         if (c.c_vpose != 0.f) g += c.c_vpose * vars[o];                            // d/dz of 1e-4 * mean(z^2) (stages 1, 2)
     } else {
@@ -451,12 +451,16 @@ static ParamsWs params_ws_carve(float* base, int hidden, int B) {
 }
 
 // grad rows: the latent columns come out of the decoder's backward (g_z), the pad columns are zero
-__global__ void params_grad_finish_kernel(const float* __restrict__ g_z, float* __restrict__ grad, int B) {
+__global__ void params_grad_finish_kernel(const float* __restrict__ g_z, const float* __restrict__ vars, float c_vpose,
+                                          float* __restrict__ grad, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * VS) return;
     const int b = i / VS, col = i - b * VS;
-    if (col < SAGA_VAR_HAND) grad[i] = g_z[(size_t)b * 128 + col];
-    else if (col >= SAGA_VAR_COUNT) grad[i] = 0.f;
+    if (col < SAGA_VAR_HAND) {
+        float g = g_z[(size_t)b * 128 + col];
+        if (c_vpose != 0.f) g += c_vpose * vars[i];          // a caller's latent regulariser (saga_params_bwd_reg)
+        grad[i] = g;
+    } else if (col >= SAGA_VAR_COUNT) grad[i] = 0.f;
 }
 
 extern "C" size_t saga_params_workspace_floats(const saga_decoder_t* d, int B) {
@@ -484,8 +488,11 @@ extern "C" int saga_params_fwd(const saga_decoder_t* d, const float* vars, float
     return 0;
 }
 
-extern "C" int saga_params_bwd(const saga_decoder_t* d, const float* vars, const float* g_full_pose, const float* g_shape,
-                               const float* g_transl, float* grad_vars, int n_shape, float* ws, int B, void* stream) {
+// saga_params_bwd with the gradient of a caller's regularisers c_vpose/2 * |latent|^2 + c_hand/2 * |hand|^2 folded into the rows
+// (internal: saga_motion_step)
+int saga_params_bwd_reg(const saga_decoder_t* d, const float* vars, const float* g_full_pose, const float* g_shape,
+                        const float* g_transl, float* grad_vars, int n_shape, float* ws, int B, float c_vpose, float c_hand,
+                        void* stream) {
     SAGA_CHECK_ARG(d, "saga_params_bwd: null decoder");
     SAGA_CHECK_ARG(B >= 0 && B <= 65535 && d->hidden <= 512 && n_shape >= 10, "saga_params_bwd: bad sizes B=%d n_shape=%d", B, n_shape);
     if (B == 0) return 0;
@@ -495,7 +502,7 @@ extern "C" int saga_params_bwd(const saga_decoder_t* d, const float* vars, const
     ParamsWs p = params_ws_carve(ws, d->hidden, B);     // h1 / h2 / jac: what saga_params_fwd left there for these vars
     Prof prof(SAGA_PROF_PARAMS_BWD, stream);
     params_bwd_kernel<<<B, PK_THREADS, 0, st>>>(vars, p.jac, d->hand_comp, g_full_pose, g_shape, g_transl, grad_vars, p.g_x6,
-                                                g_shape ? n_shape : 0, d->n_pca, RegCfg{0.f, 0.f, 0.f, 0.f});
+                                                g_shape ? n_shape : 0, d->n_pca, RegCfg{0.f, c_hand, 0.f, 0.f});
     SAGA_LAUNCH_CHECK();
     int rc;
     if ((rc = saga_launch_gemm_nt(3, p.g_x6, X6_LD, d->w3t, X6_LD, p.g_h, d->hidden, nullptr, p.h2, B, d->hidden, X6_LD, st))) return rc;
@@ -503,7 +510,27 @@ extern "C" int saga_params_bwd(const saga_decoder_t* d, const float* vars, const
         return rc;
     if ((rc = saga_launch_gemm_nt(0, p.g_h1, d->hidden, d->w1t, d->hidden, p.g_z, 128, nullptr, nullptr, B, 128, d->hidden, st))) return rc;
     const int n = B * VS;
-    params_grad_finish_kernel<<<(n + 255) / 256, 256, 0, st>>>(p.g_z, grad_vars, B);
+    params_grad_finish_kernel<<<(n + 255) / 256, 256, 0, st>>>(p.g_z, vars, c_vpose, grad_vars, B);
+    SAGA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int saga_params_bwd(const saga_decoder_t* d, const float* vars, const float* g_full_pose, const float* g_shape,
+                               const float* g_transl, float* grad_vars, int n_shape, float* ws, int B, void* stream) {
+    return saga_params_bwd_reg(d, vars, g_full_pose, g_shape, g_transl, grad_vars, n_shape, ws, B, 0.f, 0.f, stream);
+}
+
+// torch.optim.Adam's update of the variable groups in `mask` from complete gradient rows grad [B,VS] (internal: saga_motion_step)
+int saga_adam_rows(float* vars, float* adam_m, float* adam_v, const float* grad, int mask, int step, float lr, float beta1,
+                   float beta2, float eps, int B, void* stream) {
+    SAGA_CHECK_ARG(vars && adam_m && adam_v && grad && step >= 1 && B >= 0, "saga_adam_rows: bad arguments");
+    if (B == 0) return 0;
+    Prof p(SAGA_PROF_ADAM, stream);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    AdamCfg ac{mask, 0.f, (float)((double)lr / bc1), beta1, beta2, (float)sqrt(bc2), eps};
+    const int n = B * SAGA_VAR_COUNT;
+    adam_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(vars, adam_m, adam_v, grad, nullptr, ac, B, nullptr, 0);
     SAGA_LAUNCH_CHECK();
     return 0;
 }

@@ -88,13 +88,17 @@ class FittingOP:
     see ``_fitting_stage1_native``; False: the autograd composition, replayed as a graph or eager), ``graph_stage2`` ('auto':
     stage 2 replays one captured iteration when an iteration is launch-bound, i.e. up to 2,048 bodies; True / False force it),
     ``native_params`` (default True: stage 2 maps its variables to SMPL-X arguments with ``fitting.param_maps``, one operator,
-    instead of the torch VPoser MLP + 6D->aa + hand PCA; off with a ``body_smooth_loss`` hook, which takes the torch parameters)."""
+    instead of the torch VPoser MLP + 6D->aa + hand PCA; off with a ``body_smooth_loss`` hook, which takes the torch parameters),
+    ``native_stage2`` (default True: every stage-2 iteration is ONE library call, ``saga_motion_step`` -- the same operators in
+    the same order as the autograd composition of ``stage2_losses``, plus the regularisers, the weighted sum and Adam, with no
+    PyTorch kernel in the loop; needs ``sparse_backward``, ``fused_terms``, ``native_params`` and no ``body_smooth_loss`` hook,
+    else the autograd composition runs)."""
 
     def __init__(self, fittingconfig):
         cfg = dict(T=61, gender='male', device='cuda', n_seq=1, start_t=30, init_lr_stage1=0.1, init_lr_stage2=0.01,
                    num_iter=[100, 300], body_model_path='./body_utils/body_models', vposer=None, smplx_kwargs={},
                    indices=None, body_smooth_loss=None, sparse_backward=True, reduced_forward=True, fused_terms=True,
-                   native_stage1=True, graph_stage1=True, graph_stage2='auto', native_params=True,
+                   native_stage1=True, graph_stage1=True, graph_stage2='auto', native_params=True, native_stage2=True,
                    stage1_weight_loss_rec_markers=1.0, stage1_weight_loss_vposer=0.02, stage1_weight_loss_shape=0.01,
                    stage1_weight_loss_hand=0.01,
                    stage2_weight_loss_rec_markers=0.1, stage2_weight_loss_end_markers_fit=10, stage2_weight_loss_vposer=0.02,
@@ -500,6 +504,9 @@ class FittingOP:
         params = [self.transl_opt_T, self.rot_6d_opt_T, self.other_params_opt_T]
         args = (markers_rec_T, markers_end_new, rhand_verts, contact_lbl_rec, contact_object, contact_markers, normal_object, verts_object)
 
+        if self._stage2_native_ok():
+            return self._fitting_stage2_native(args, record)
+
         def iteration():
             self.optimizer_s2.zero_grad(set_to_none=True)
             total, terms = self.stage2_losses(*args)
@@ -548,6 +555,106 @@ class FittingOP:
             g.replay()
             if record is not None:             # (the graph's output tensors: valid until the next replay)
                 record(step, total.clone(), {k: v.clone() for k, v in terms.items()})
+        return self.transl_opt_T, self.rot_6d_opt_T, self.shape_T, self.other_params_opt_T
+
+    # ---- stage 2 as one library call per iteration ----------------------------------------------------------------------------
+    def _stage2_native_ok(self):
+        return bool(self.native_stage2 and self.native_params and self.fused_terms and self.sparse_backward
+                    and self.body_smooth_loss is None and hasattr(self.vposer_model, 'bodyprior_dec_fc1'))
+
+    def pack_stage2_vars(self):
+        """The whole-sequence variables as ``saga_motion_step``'s packed rows [S*T, 112] (a copy)."""
+        S, T = self.n_seq, self.T
+        other = self.other_params_opt_T.detach()
+        return torch.cat([other.reshape(S * T, -1), other.new_zeros(S * T, 6), self.shape_T.reshape(S * T, -1),
+                          self.transl_opt_T.detach().reshape(S * T, 3), self.rot_6d_opt_T.detach().reshape(S * T, 6),
+                          other.new_zeros(S * T, _lib.VAR_STRIDE - 105)], dim=1).contiguous()
+
+    def unpack_stage2_vars(self, packed):
+        S, T, sl = self.n_seq, self.T, _lib.VAR_SLICES
+        with torch.no_grad():
+            self.other_params_opt_T.copy_(packed[:, :80].reshape(S, T, 80))
+            self.transl_opt_T.copy_(packed[:, sl['transl_rec'][0]:sl['transl_rec'][1]].reshape(S, T, 3))
+            self.rot_6d_opt_T.copy_(packed[:, sl['glo_rot_rec'][0]:sl['glo_rot_rec'][1]].reshape(S, T, 6))
+
+    def stage2_native_setup(self, markers_rec_T, markers_end_new, rhand_verts, contact_lbl_rec, contact_object, contact_markers,
+                            normal_object, verts_object):
+        """Handles, device tables, targets and workspace of ``saga_motion_step`` for these (device, float32, shaped as
+        ``fitting_stage2`` shapes them) targets -> a context for :meth:`stage2_native_step`."""
+        S, T, dev = self.n_seq, self.T, self.device
+        if self._picker is None:
+            self._make_picker(rhand_verts)
+        pk, lm = self._picker, self._loss_model
+        if pk.rows.names != ['markers', 'feet', 'markers_143_tail', 'rhand_tail']:
+            raise RuntimeError('native_stage2: unexpected pick sets %s' % (pk.rows.names,))
+        if lm is not None:
+            bm, grad_ids, rh_rows, mk_rows = lm['bm'], lm['grad_rows'], lm['rhand'], lm['markers_143']
+        else:
+            bm, grad_ids, rh_rows, mk_rows = self.smplx_model_batch, pk.union, rhand_verts, self.markers_ids_143
+        _, hs = bm._grad_subset(grad_ids, dev)
+        O, n_tail = verts_object.shape[-2], T - self.start_t
+        c = lambda t: t.detach().float().contiguous()
+        keep = dict(markers_rec=c(markers_rec_T), markers_end=c(markers_end_new), contact_lbl=c(contact_lbl_rec),
+                    contact_object=c(contact_object), contact_markers=c(contact_markers), verts_object=c(verts_object),
+                    normal_object=c(normal_object))
+        mask = torch.ones(len(self.markers_ids), device=dev)              # (:360-364: hand, forearm, fingers out)
+        mask[49:49 + 6] = 0
+        mask[33:33 + 6] = 0
+        mask[69:] = 0
+        keep.update(mask=mask, hand_sel=rh_rows.to(torch.int32).contiguous(), palm_sel=mk_rows[-22:].to(torch.int32).contiguous())
+        P = _lib.ptr
+        tabs = pk.rows.tables(dev)
+        tables = _lib.MotionTables(hand_normal_sel=P(keep['hand_sel']), palm_normal_sel=P(keep['palm_sel']), marker_mask=P(mask))
+        for k, (tb, n, t0) in enumerate(zip(tabs, pk.rows.sizes, pk.rows.t0)):
+            tables.sets[k] = _lib.PickSet(pos=P(tb[0]), inv_ptr=P(tb[1]), inv_idx=P(tb[2]), n=n, t0=t0)
+        prob = _lib.MotionProblem(**{k: P(keep[k]) for k in ('markers_rec', 'markers_end', 'contact_lbl', 'contact_object',
+                                                             'contact_markers', 'verts_object', 'normal_object')})
+        cfg = _lib.MotionStepCfg(beta1=0.9, beta2=0.999, eps=1e-8, lr=float(self.init_lr_stage2), adam_step=0,
+                                 **{'w_' + k: float(getattr(self, 'stage2_weight_loss_' + k)) for k in _lib.MOTION_WEIGHTS})
+        cfg.terms = _lib.MotionTermsCfg(n_seq=S, n_frames=T, n_tail=n_tail, n_markers=len(self.markers_ids),
+                                        foot_group_size=(ctypes.c_int32 * 4)(*pk.foot_sizes), n_hand=int(rh_rows.shape[0]), n_obj=O,
+                                        n_contact_markers=len(self.markers_ids_143), n_palm=22, n_last_frames=5, vel_thres=0.1)
+        lib = _lib.load()
+        h, dec = bm.handle(dev), self._decoder_handle()
+        n = lib.saga_motion_step_workspace_floats(h, hs, dec, ctypes.byref(cfg))
+        if n == 0:
+            raise RuntimeError('saga_motion_step_workspace_floats: %s' % lib.saga_last_error().decode())
+        return dict(bm=bm, h=h, hs=hs, dec=dec, tables=tables, prob=prob, cfg=cfg, keep=keep, ws=torch.empty(n, device=dev),
+                    loss=torch.empty(S, device=dev), terms=torch.empty(S, 16, device=dev))
+
+    def stage2_native_step(self, ctx, packed, adam_m=None, adam_v=None, adam_step=0, lr=None):
+        """One ``saga_motion_step`` on the packed rows (``adam_step`` 0: objective and gradient only) -> (loss [S], terms [S,16]:
+        views of the context's buffers, valid until the next call)."""
+        cfg = ctx['cfg']
+        cfg.adam_step = int(adam_step)
+        if lr is not None:
+            cfg.lr = float(lr)
+        P = _lib.ptr
+        _lib.call('saga_motion_step', self.device, ctx['h'], ctx['hs'], ctx['dec'], ctypes.byref(ctx['tables']), ctypes.byref(ctx['prob']),
+                  ctypes.byref(cfg), P(packed), P(adam_m), P(adam_v), P(ctx['ws']), P(ctx['loss']), P(ctx['terms']))
+        return ctx['loss'], ctx['terms']
+
+    def stage2_native_buffer(self, ctx, name, shape, dtype=torch.float32):
+        """A named intermediate of the last ``stage2_native_step`` inside the context's workspace (a view)."""
+        off = _lib.load().saga_motion_step_workspace_offset(ctx['h'], ctx['hs'], ctx['dec'], ctypes.byref(ctx['cfg']), name.encode())
+        if off < 0:
+            raise KeyError(name)
+        n = int(np.prod(shape))
+        return ctx['ws'][off:off + n].view(dtype).reshape(shape)
+
+    def _fitting_stage2_native(self, args, record):
+        ctx = self.stage2_native_setup(*args)
+        packed = self.pack_stage2_vars()
+        m, v = torch.zeros_like(packed), torch.zeros_like(packed)
+        lr = float(self.init_lr_stage2)
+        for step in range(self.num_iter[1]):
+            if step > 150:
+                lr = 0.005
+            total, terms = self.stage2_native_step(ctx, packed, m, v, step + 1, lr)
+            if record is not None:
+                record(step, total.clone(), {k: terms[:, i].clone() for i, k in enumerate(_lib.MOTION_STEP_TERMS) if i > 0})
+        self.unpack_stage2_vars(packed)
+        self.last_stage2 = ctx
         return self.transl_opt_T, self.rot_6d_opt_T, self.shape_T, self.other_params_opt_T
 
     def fitting(self, body_markers_rec, markers_end_new, rhand_verts, contact_lbl_rec, contact_object, contact_markers,

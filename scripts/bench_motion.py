@@ -18,6 +18,7 @@ ap.add_argument('--iters', type=int, default=5)
 ap.add_argument('--warmup', type=int, default=2)
 ap.add_argument('--dense-backward', action='store_true', help='dense [S*T,V,3] vertex gradient (the form the reference has)')
 ap.add_argument('--full-forward', action='store_true', help='evaluate the whole mesh in the forward (reduced_forward=False)')
+ap.add_argument('--autograd', action='store_true', help='the autograd composition of the operators instead of saga_motion_step (native_stage2=False)')
 ap.add_argument('--mesh-faces', action='store_true', help='mesh-like synthetic model (id-local faces and weights)')
 ap.add_argument('--whole-fit', action='store_true', help='time a whole two-stage fit (T x 100 stage-1 iterations, 300 stage-2 iterations)')
 a = ap.parse_args()
@@ -26,7 +27,8 @@ tmp = tempfile.TemporaryDirectory()
 write_body_model(tmp.name, gender='male', seed=7, mesh_faces=a.mesh_faces, local_weights=a.mesh_faces)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from workloads import motion_stage2
-op, run_n = motion_stage2(tmp.name, S, T, start_t, sparse_backward=not a.dense_backward, reduced_forward=not a.full_forward)
+op, run_n = motion_stage2(tmp.name, S, T, start_t, sparse_backward=not a.dense_backward, reduced_forward=not a.full_forward,
+                           native_stage2=not a.autograd)
 dd = op.bench_data
 idx, markers_rec, markers_end, lbl, c_obj, c_mk, no, vo = (dd[k] for k in ('idx', 'markers_rec', 'markers_end', 'lbl', 'c_obj', 'c_mk', 'no', 'vo'))
 if a.whole_fit:
@@ -55,7 +57,8 @@ t0 = time.perf_counter()
 run(a.iters)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.iters
-print(json.dumps({'config': 'GraspMotion-Opt stage 2, %d sequences x %d frames' % (S, T), 'bodies_per_iteration': S * T, 'backward': 'dense' if a.dense_backward else 'loss vertices only',
+print(json.dumps({'config': 'GraspMotion-Opt stage 2, %d sequences x %d frames' % (S, T), 'bodies_per_iteration': S * T,
+                  'iteration': 'saga_motion_step' if op._stage2_native_ok() else 'autograd composition', 'backward': 'dense' if a.dense_backward else 'loss vertices only',
                   'vertices_evaluated': (op._loss_model['bm'].num_verts if op._loss_model is not None else op.smplx_model_batch.num_verts),
                   'model': 'mesh-like faces, local weights' if a.mesh_faces else 'SURVEY synthetic (random faces and joints)',
                   'ms_per_iteration': round(dt * 1e3, 2), 'frame_iterations_per_s': round(S * T / dt, 1),

@@ -159,3 +159,46 @@ def test_config5_full_mesh_chamfer_at_full_size():
         bs = slice(b0, b0 + 128)
         dd = ((x[bs][:, qs, None, :] - y[bs][:, None, ps, :]) ** 2).sum(-1)              # [128, 256, 4096]
         assert (dd.min(dim=2).values >= d1[bs][:, qs] * (1 - 1e-6)).all()
+
+
+def test_config4_motion_stage2_iteration_at_full_size(body_model_dir):
+    """BASELINE config 4 at its full size under pytest: ONE GraspMotion-Opt stage-2 iteration (saga_motion_step: objective,
+    backward, Adam) of S = 256 sequences x T = 61 frames = 15,616 bodies.  The fp64 oracle cannot follow at this size (it is
+    checked against this path at S = 2 in test_gpu_motion.py); here the size-independent property: a sequence's result does not
+    depend on the batch it is in -- sequences 0, 100 and 255 of the S = 256 run are BIT-EQUAL (objective, every term, updated
+    variables, Adam moments) to an S = 3 run on those three sequences alone."""
+    import os
+    import sys
+    from saga_amd import _lib
+    from saga_amd.motion_fitting import FittingOP
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'scripts'))
+    import workloads as wl
+    S, T, start_t, pick = 256, 61, 30, [0, 100, 255]
+    op, _ = wl.motion_stage2(body_model_dir, S=S, T=T, start_t=start_t)
+    d = op.bench_data
+    rh = torch.as_tensor(d['rhand'], dtype=torch.long, device='cuda')
+
+    def one_iteration(o, sel):
+        n = len(sel)
+        args = (d['markers_rec'][sel].cuda().float(), d['markers_end'][sel].cuda().float(), rh, d['lbl'][sel].cuda().float(),
+                d['c_obj'][sel].cuda().float(), d['c_mk'][sel].cuda().float(), d['no'][sel].cuda().float(), d['vo'][sel].cuda().float())
+        o._make_picker(rh)
+        ctx = o.stage2_native_setup(*args)
+        packed = o.pack_stage2_vars()
+        m, v = torch.zeros_like(packed), torch.zeros_like(packed)
+        loss, terms = o.stage2_native_step(ctx, packed, m, v, adam_step=1, lr=0.01)
+        torch.cuda.synchronize()
+        r = lambda t: t.reshape(n, T, -1)
+        return loss.clone(), terms.clone(), r(packed), r(m), r(v)
+
+    full = one_iteration(op, list(range(S)))
+    assert torch.isfinite(full[0]).all() and (full[1][:, 1:10] > 0).any(dim=0).all()          # every term is active at this size
+    op3 = FittingOP(dict(T=T, n_seq=len(pick), start_t=start_t, gender='male', device='cuda', smplx_beta=op.shape_t[pick].cpu().numpy(),
+                         num_iter=[0, 1], markers_ids=d['idx']['markers_f0_p5'], markers_ids_143=d['idx']['markers_143'],
+                         body_model_path=body_model_dir, indices=d['idx']))
+    op3.init_param_T(op.transl_opt_T.detach()[pick], op.rot_6d_opt_T.detach()[pick], op.other_params_opt_T.detach()[pick],
+                     op.shape_T[pick].cpu().numpy())
+    small = one_iteration(op3, pick)
+    for name, a, b in zip(('loss', 'terms', 'variables', 'exp_avg', 'exp_avg_sq'), full, small):
+        assert torch.equal(a[pick], b), name
+    assert not torch.equal(full[2][pick], op3.pack_stage2_vars().reshape(len(pick), T, -1))      # the update moved the variables

@@ -468,7 +468,7 @@ def test_motion_stage2_graph_replay_matches_eager(body_model_dir):
     res = {}
     for mode, flag in [('graph', True), ('eager', False)]:
         op = _hip_op(body_model_dir, idx, vposer, prob, S, Tn, start_t, [0, n2])
-        op.graph_stage2 = flag
+        op.graph_stage2, op.native_stage2 = flag, False          # (the autograd composition; saga_motion_step is checked below)
         op.init_param_T(transl, rot6, other, shape.numpy())
         hist = []
         out = op.fitting_stage2(prob['markers_rec'], prob['markers_end'], idx['rhand'], prob['lbl'], prob['c_obj'], prob['c_mk'],
@@ -485,6 +485,113 @@ def test_motion_stage2_graph_replay_matches_eager(body_model_dir):
     assert not torch.equal(res['graph'][0][0][0], res['graph'][0][-1][0])          # the totals move from iteration to iteration
     for a, b in zip(res['graph'][1], res['eager'][1]):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-3, rtol=0)
+
+
+def _stage2_start(S, Tn, prob, seed=9):
+    g = torch.Generator().manual_seed(seed)
+    lam = torch.linspace(0, 1, Tn)[None, :, None]
+    transl = torch.tensor([0.0, 0.4, 1.0]) + 0.02 * lam + 0.002 * torch.randn(S, Tn, 3, generator=g)
+    rot6 = torch.tensor([-1., 0, 0, 0, 0, 1]).expand(S, Tn, 6) + 0.05 * torch.randn(S, Tn, 6, generator=g)
+    other = 0.1 * torch.randn(S, 1, 80, generator=g) + 0.05 * lam * torch.randn(S, 1, 80, generator=g)
+    shape = prob['beta'][:, None].expand(S, Tn, 10).float().contiguous()
+    return transl, rot6, other, shape
+
+
+@pytest.mark.parametrize('reduced', [True, False])
+def test_motion_step_terms_bit_equal_autograd_composition(body_model_dir, reduced):
+    """saga_motion_step (the whole stage-2 iteration as ONE library call) against the autograd composition of the same operators
+    (``stage2_losses``, itself checked against the oracle): the seven geometric terms BIT-EQUAL (same kernels, same order, same
+    inputs), the two regularisers and the total within 1e-6 relative (torch's mean against the library's fixed-order sum), the
+    gradient rows within 1e-6 of autograd's (bit-equal except where the regulariser gradient is added), every named intermediate
+    equal; on the loss-vertex body model (default) and on the full mesh.  skating / contact / collision / angle active."""
+    from saga_amd import _lib
+    S, Tn, start_t = 2, 13, 6
+    idx, _, vposer, prob = _fit_problem(body_model_dir, S, Tn, start_t, seed=20)
+    transl, rot6, other, shape = _stage2_start(S, Tn, prob)
+    f = lambda a, *sh: torch.as_tensor(a).cuda().float().reshape(*sh)
+    rh = torch.as_tensor(idx['rhand'], dtype=torch.long, device='cuda')
+    vo = f(prob['vo'], S, Tn - start_t, 2048, 3).clone()
+    op = _hip_op(body_model_dir, idx, vposer, prob, S, Tn, start_t, [0, 1])
+    op.reduced_forward = reduced
+    op.init_param_T(transl, rot6, other, shape.numpy())
+    from saga_amd.motion_fitting import convert_to_3D_rot, gen_body_mesh_v1
+    with torch.no_grad():       # object points 4 mm from the palm markers of the last frames: the angle term is active
+        p = convert_to_3D_rot(torch.cat([op.transl_opt_T, op.rot_6d_opt_T, op.shape_T, op.other_params_opt_T], -1).reshape(S * Tn, -1))
+        v = gen_body_mesh_v1(p, op.smplx_model_batch, op.vposer_model)[0].reshape(S, Tn, -1, 3)
+        vo[:, :, :22] = v[:, start_t:, op.markers_ids_143[-22:]] + 0.004
+    args = (f(prob['markers_rec'], S, Tn, -1, 3), f(prob['markers_end'], S, -1, 3), rh, f(prob['lbl'], S, Tn, 4), f(prob['c_obj'], S, -1),
+            f(prob['c_mk'], S, -1), f(prob['no'], S, Tn - start_t, 2048, 3), vo)
+    total, terms = op.stage2_losses(*args)
+    total.sum().backward()
+    assert (op._loss_model is not None) == reduced
+    ctx = op.stage2_native_setup(*args)
+    packed = op.pack_stage2_vars()
+    before = packed.clone()
+    loss, out = op.stage2_native_step(ctx, packed)                  # adam_step 0: objective and gradient only
+    assert torch.equal(packed, before)
+    col = {k: out[:, i] for i, k in enumerate(_lib.MOTION_STEP_TERMS)}
+    for k in ('rec_markers', 'end_markers_fit', 'skating', 'hand_smooth', 'contact', 'collision', 'hand_angle'):
+        assert torch.equal(col[k], terms[k].detach()), k
+        assert (col[k] > 0).all(), k
+    for k in ('vposer', 'hand'):
+        np.testing.assert_allclose(col[k].cpu().numpy(), terms[k].detach().cpu().numpy(), rtol=1e-6, err_msg=k)
+    np.testing.assert_allclose(loss.cpu().numpy(), total.detach().cpu().numpy(), rtol=1e-6)
+    assert torch.equal(loss, col['total'])
+    grad = op.stage2_native_buffer(ctx, 'grad', (S, Tn, _lib.VAR_STRIDE))
+    sl = _lib.VAR_SLICES
+    for name, got, ref in [('transl', grad[..., sl['transl_rec'][0]:sl['transl_rec'][1]], op.transl_opt_T.grad),
+                           ('rot6d', grad[..., sl['glo_rot_rec'][0]:sl['glo_rot_rec'][1]], op.rot_6d_opt_T.grad),
+                           ('other', grad[..., :80], op.other_params_opt_T.grad)]:
+        assert ref.abs().max() > 0
+        assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 1e-6, name
+        if name != 'other':       # no regulariser on these: the same kernels on the same numbers
+            assert torch.equal(got, ref), name
+    assert grad[..., sl['betas'][0]:sl['betas'][1]].abs().max() > 0 and grad[..., 105:].abs().max() == 0
+    # run-to-run bit-equal, and an update moves exactly the variables the reference's optimiser owns (:344-350)
+    g0 = grad.clone()
+    loss2, _ = op.stage2_native_step(ctx, packed)
+    assert torch.equal(loss2, loss) and torch.equal(op.stage2_native_buffer(ctx, 'grad', (S, Tn, _lib.VAR_STRIDE)), g0)
+    m, v2 = torch.zeros_like(packed), torch.zeros_like(packed)
+    op.stage2_native_step(ctx, packed, m, v2, adam_step=1, lr=0.01)
+    moved = (packed != before).reshape(S * Tn, -1)
+    assert moved[:, :80].any() and moved[:, 96:105].all() and not moved[:, 80:96].any() and not moved[:, 105:].any()
+    # Adam's first step is -lr * g / (|g| + eps) per element
+    g_rows = g0.reshape(S * Tn, -1)
+    expect = before - 0.01 * g_rows / (g_rows.abs() + 1e-8)
+    np.testing.assert_allclose(packed[:, 96:105].cpu().numpy(), expect[:, 96:105].cpu().numpy(), atol=1e-6)
+
+
+def test_motion_stage2_native_loop_matches_autograd_loop(body_model_dir):
+    """``fitting_stage2`` through saga_motion_step (the default) against the eager autograd loop with torch.optim.Adam: first
+    iteration equal to 1e-6, later totals within 5e-3 and variables within 2e-3 after 6 iterations (the bars of the graph-replay
+    test: the collision / skating / angle masks are discontinuous), through the learning-rate switch logic."""
+    S, Tn, start_t, n2 = 2, 9, 4, 6
+    idx, _, vposer, prob = _fit_problem(body_model_dir, S, Tn, start_t, seed=60)
+    g = torch.Generator().manual_seed(5)
+    transl = torch.tensor([0.0, 0.4, 1.0]) + 0.02 * torch.rand(S, Tn, 3, generator=g)
+    rot6 = torch.tensor([-1., 0, 0, 0, 0, 1]).expand(S, Tn, 6) + 0.05 * torch.randn(S, Tn, 6, generator=g)
+    other = 0.1 * torch.randn(S, Tn, 80, generator=g)
+    shape = prob['beta'][:, None].expand(S, Tn, 10).float().contiguous()
+    res = {}
+    for mode in ('native', 'eager'):
+        op = _hip_op(body_model_dir, idx, vposer, prob, S, Tn, start_t, [0, n2])
+        op.native_stage2, op.graph_stage2 = mode == 'native', False
+        op.init_param_T(transl, rot6, other, shape.numpy())
+        hist = []
+        out = op.fitting_stage2(prob['markers_rec'], prob['markers_end'], idx['rhand'], prob['lbl'], prob['c_obj'], prob['c_mk'],
+                                prob['no'], prob['vo'], record=lambda i, tot, terms: hist.append((tot.cpu(), {k: v.cpu() for k, v in terms.items()})))
+        assert (mode == 'native') == hasattr(op, 'last_stage2')
+        res[mode] = (hist, [t.detach().clone() for t in out])
+    assert len(res['native'][0]) == n2 and set(res['native'][0][0][1]) == set(res['eager'][0][0][1])
+    for i, ((tn, dn), (te, de)) in enumerate(zip(res['native'][0], res['eager'][0])):
+        np.testing.assert_allclose(tn.numpy(), te.numpy(), rtol=1e-6 if i == 0 else 5e-3, err_msg='iteration %d' % i)
+        if i == 0:
+            for k in de:
+                np.testing.assert_allclose(dn[k].numpy(), de[k].numpy(), rtol=1e-6, atol=1e-9, err_msg=k)
+    assert not torch.equal(res['native'][0][0][0], res['native'][0][-1][0])
+    for a, b in zip(res['native'][1], res['eager'][1]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-3, rtol=0)
+    assert not torch.equal(res['native'][1][0], transl.cuda())
 
 
 def test_motion_fitting_sequences_are_independent(body_model_dir):
