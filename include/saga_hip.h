@@ -467,7 +467,7 @@ int saga_fit_best_update(const float* loss, const float* vars, const float* mark
  * Whole GraspMotion-Opt stage-2 iteration on the device.  Replaces, for S independent sequences of T frames, one pass of the
  * loop body of FittingOP.fitting_stage2 (MotionFill/models/fittingop.py:342-414: zero_grad, the objective :356-409 with its
  * helpers :132-280, loss.backward, optimizer.step) with no host work and no framework kernel between the launches:
- *   saga_params_fwd, saga_smplx_fwd_selected, saga_pick_sets_fwd, saga_vertex_normals_subset_window (hand, palm markers),
+ *   saga_params_fwd, saga_smplx_fwd_selected, saga_pick_sets_fwd, saga_vertex_normals_subset_window (hand + palm markers),
  *   saga_p2p_signed_fwd x2 (markers -> object :154, object -> hand :157), saga_motion_terms_fwd, the two regularisers and the
  *   weighted sum (:391-409), the reverse of each, and torch.optim.Adam's update (:344-350; no weight decay) of transl, rot6d,
  *   the VPoser latent and the hand coefficients.  The learned smoothness prior (:70-130) is not part of it.
@@ -480,8 +480,8 @@ int saga_fit_best_update(const float* loss, const float* vars, const float* mark
  *   tables  DEVICE index arrays: the four pick sets out of m_grad's rows -- 0: markers [M] (every frame), 1: the four heel / toe
  *           groups side by side in contact_lbl's column order (every frame), 2: the contact markers [CM] (frames T-n_tail..),
  *           3: the right hand [H] (frames T-n_tail..) -- each with pos, inv_ptr, inv_idx, n, t0 (out / g_out are ignored);
- *           hand_normal_sel [H] / palm_normal_sel [NP]: rows of m's vertices of the right hand (order of set 3) and of the
- *           last NP contact markers; marker_mask [M] (:360-364)
+ *           normal_sel [H+NP]: rows of m's vertices of the right hand (order of set 3), then of the last NP contact markers
+ *           (the vertices whose normals the terms read); marker_mask [M] (:360-364)
  *   problem DEVICE targets: markers_rec [S,T,M,3], markers_end [S,M,3], contact_lbl [S,T,4], contact_object [S,O],
  *           contact_markers [S,CM], verts_object / normal_object [S,n_tail,O,3]
  *   cfg     sizes (terms), the nine stage2_weight_loss_* weights (opt_graspmotion.py:470-495), Adam state: adam_step is the
@@ -497,8 +497,7 @@ int saga_fit_best_update(const float* loss, const float* vars, const float* mark
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     saga_pick_set_t sets[4];
-    const int32_t* hand_normal_sel;
-    const int32_t* palm_normal_sel;
+    const int32_t* normal_sel;
     const float* marker_mask;
 } saga_motion_tables_t;
 typedef struct {

@@ -68,7 +68,7 @@ MOTION_NTERMS = 12
 
 class MotionTables(ctypes.Structure):
     """saga_motion_tables_t"""
-    _fields_ = [('sets', PickSet * 4), ('hand_normal_sel', ctypes.c_void_p), ('palm_normal_sel', ctypes.c_void_p),
+    _fields_ = [('sets', PickSet * 4), ('normal_sel', ctypes.c_void_p),
                 ('marker_mask', ctypes.c_void_p)]
 
 

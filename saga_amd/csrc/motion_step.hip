@@ -5,7 +5,7 @@
 //   packed variable rows [S*T,112] -> SMPL-X arguments            saga_params_fwd (VPoser MLP, 6D -> aa, hand PCA)
 //   bodies over the vertices the objective reads                   saga_smplx_fwd_selected (m = loss model, m_grad = its union)
 //   marker / foot / contact-marker / hand rows                     saga_pick_sets_fwd (one launch)
-//   hand + palm-marker normals on the frames start_t..             saga_vertex_normals_subset_window (x2)
+//   hand + palm-marker normals on the frames start_t..             saga_vertex_normals_subset_window
 //   markers -> object, object -> hand signed distances             saga_p2p_signed_fwd (x2, one direction each: :154-158)
 //   the seven geometric terms                                      saga_motion_terms_fwd
 //   regularisers + weighted sum (:391-409)                         motion_total_kernel (below)
@@ -20,6 +20,8 @@
 int saga_params_bwd_reg(const saga_decoder_t* d, const float* vars, const float* g_full_pose, const float* g_shape,
                         const float* g_transl, float* grad_vars, int n_shape, float* ws, int B, float c_vpose, float c_hand,
                         void* stream);
+int saga_vertex_normals_window_split(const saga_model_t* m, const float* verts, const int32_t* sel, int n_a, int n_b, float* normals_a,
+                                     float* normals_b, int S, int T, int t0, void* stream);
 int saga_adam_rows(float* vars, float* adam_m, float* adam_v, const float* grad, int mask, int step, float lr, float beta1,
                    float beta2, float eps, int B, void* stream);
 
@@ -179,7 +181,7 @@ extern "C" int saga_motion_step(const saga_model_t* m, const saga_model_t* m_gra
     SAGA_CHECK_ARG(tb && prob && vars && ws && loss, "saga_motion_step: null argument");
     SAGA_CHECK_ARG(cfg->adam_step >= 0 && (cfg->adam_step == 0 || (adam_m && adam_v)), "saga_motion_step: adam step %d / null moments",
                    cfg->adam_step);
-    SAGA_CHECK_ARG(tb->hand_normal_sel && tb->palm_normal_sel && tb->marker_mask, "saga_motion_step: incomplete tables");
+    SAGA_CHECK_ARG(tb->normal_sel && tb->marker_mask, "saga_motion_step: incomplete tables");
     SAGA_CHECK_ARG(prob->markers_rec && prob->markers_end && prob->contact_lbl && prob->contact_object && prob->contact_markers &&
                        prob->verts_object && prob->normal_object,
                    "saga_motion_step: incomplete problem");
@@ -201,8 +203,8 @@ extern "C" int saga_motion_step(const saga_model_t* m, const saga_model_t* m_gra
     float* outs[4] = {w.markers, w.feet, w.mk_tail, w.hand_tail};
     for (int k = 0; k < 4; ++k) { sets[k] = tb->sets[k]; sets[k].out = outs[k]; sets[k].g_out = nullptr; }
     if ((rc = saga_pick_sets_fwd(w.verts_sel, sets, 4, S, T, U, stream))) return rc;
-    if ((rc = saga_vertex_normals_subset_window(m, w.verts, tb->hand_normal_sel, c.n_hand, w.nrm_hand, S, T, t0, stream))) return rc;
-    if ((rc = saga_vertex_normals_subset_window(m, w.verts, tb->palm_normal_sel, c.n_palm, w.nrm_palm, S, T, t0, stream))) return rc;
+    if ((rc = saga_vertex_normals_window_split(m, w.verts, tb->normal_sel, c.n_hand, c.n_palm, w.nrm_hand, w.nrm_palm, S, T, t0, stream)))
+        return rc;
     // (:154) markers -> object: signed by the object normals, with the difference vectors; the object -> marker direction is discarded
     if ((rc = saga_p2p_signed_fwd(w.mk_tail, prob->verts_object, nullptr, prob->normal_object, nullptr, w.h2o_marker, nullptr, w.idx_m2o,
                                   nullptr, w.h2o_vec, N, c.n_contact_markers, c.n_obj, stream)))

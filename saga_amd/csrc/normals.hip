@@ -14,7 +14,7 @@ void saga_prof_end(void* scope);
 
 __global__ void vertex_normals_kernel(const float* __restrict__ verts, const int32_t* __restrict__ vf_ptr,
                                       const int32_t* __restrict__ vf_tri, const int32_t* __restrict__ sel, int n_out,
-                                      float* __restrict__ normals, int V, int T, int t0) {
+                                      float* __restrict__ normals, int V, int T, int t0, int n_a, float* __restrict__ normals_b) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (o >= n_out) return;
@@ -22,7 +22,8 @@ __global__ void vertex_normals_kernel(const float* __restrict__ verts, const int
     float nx, ny, nz;
     const int row = (b / (T - t0)) * T + t0 + b % (T - t0);       // output b = frame t0 + b % (T - t0) of sequence b / (T - t0)
     saga_vertex_normal(verts + (size_t)row * V * 3, vf_ptr, vf_tri, v, nx, ny, nz);
-    float* out = normals + ((size_t)b * n_out + o) * 3;
+    // outputs 0..n_a-1 -> normals [B,n_a,3], the rest -> normals_b [B,n_out-n_a,3] (n_a = n_out: one array)
+    float* out = o < n_a ? normals + ((size_t)b * n_a + o) * 3 : normals_b + ((size_t)b * (n_out - n_a) + (o - n_a)) * 3;
     out[0] = nx; out[1] = ny; out[2] = nz;
 }
 
@@ -33,7 +34,8 @@ __global__ void vertex_normals_kernel(const float* __restrict__ verts, const int
 #define VNL_THREADS 512
 __global__ __launch_bounds__(VNL_THREADS) void vertex_normals_lds_kernel(const float* __restrict__ verts, const int32_t* __restrict__ vf_ptr,
                                                                          const int32_t* __restrict__ vf_tri, const int32_t* __restrict__ sel,
-                                                                         int n_out, float* __restrict__ normals, int V, int T, int t0) {
+                                                                         int n_out, float* __restrict__ normals, int V, int T, int t0,
+                                                                         int n_a, float* __restrict__ normals_b) {
     extern __shared__ __attribute__((aligned(16))) float vnl_smem[];     // [3 + V*3]
     const int b = blockIdx.x, tid = threadIdx.x;
     const int row = (b / (T - t0)) * T + t0 + b % (T - t0);
@@ -69,14 +71,15 @@ __global__ __launch_bounds__(VNL_THREADS) void vertex_normals_lds_kernel(const f
                 if (e + u < e1) saga_face_normal_add(sv, t[u].x, t[u].y, t[u].z, nn);
         }
         saga_normal_finish(nn);
-        float* out = normals + ((size_t)b * n_out + o) * 3;
+        float* out = o < n_a ? normals + ((size_t)b * n_a + o) * 3 : normals_b + ((size_t)b * (n_out - n_a) + (o - n_a)) * 3;
         out[0] = nn[0]; out[1] = nn[1]; out[2] = nn[2];
     }
 }
 
 // B outputs; T, t0: verts holds sequences of T meshes and output b is mesh t0 + b % (T - t0) of sequence b / (T - t0) (1, 0: mesh b)
 static int launch(const saga_model_t* m, const float* verts, const int32_t* sel, int n_out, float* normals, int B, int T, int t0,
-                  void* stream) {
+                  void* stream, int n_a = -1, float* normals_b = nullptr) {
+    if (n_a < 0) n_a = n_out;
     SAGA_CHECK_ARG(m && m->F > 0, "saga_vertex_normals: model has no faces");
     SAGA_CHECK_DEVICE(m, "saga_vertex_normals");
     SAGA_CHECK_ARG(B >= 0 && B <= 65535 && n_out >= 0, "saga_vertex_normals: bad sizes B=%d n=%d", B, n_out);
@@ -95,9 +98,11 @@ static int launch(const saga_model_t* m, const float* verts, const int32_t* sel,
     dim3 grid((n_out + 255) / 256, B);
     void* prof = saga_prof_begin(SAGA_PROF_NORMALS, stream);
     if (staged)
-        vertex_normals_lds_kernel<<<B, VNL_THREADS, lds, (hipStream_t)stream>>>(verts, m->vf_ptr, m->vf_tri, sel, n_out, normals, m->V, T, t0);
+        vertex_normals_lds_kernel<<<B, VNL_THREADS, lds, (hipStream_t)stream>>>(verts, m->vf_ptr, m->vf_tri, sel, n_out, normals, m->V, T, t0, n_a,
+                                                                                normals_b);
     else
-        vertex_normals_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(verts, m->vf_ptr, m->vf_tri, sel, n_out, normals, m->V, T, t0);
+        vertex_normals_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(verts, m->vf_ptr, m->vf_tri, sel, n_out, normals, m->V, T, t0, n_a,
+                                                                     normals_b);
     saga_prof_end(prof);
     SAGA_LAUNCH_CHECK();
     return 0;
@@ -120,6 +125,16 @@ extern "C" int saga_vertex_normals_subset_window(const saga_model_t* m, const fl
     SAGA_CHECK_ARG(sel || n_sel == 0, "saga_vertex_normals_subset_window: null selection");
     SAGA_CHECK_ARG(S >= 0 && T > 0 && t0 >= 0 && t0 < T, "saga_vertex_normals_subset_window: bad sizes S=%d T=%d t0=%d", S, T, t0);
     return launch(m, verts, sel, n_sel, normals, S * (T - t0), T, t0, stream);
+}
+
+// the same with the outputs split into two arrays: sel[0..n_a) -> normals_a [S,T-t0,n_a,3], sel[n_a..n_a+n_b) -> normals_b
+// [S,T-t0,n_b,3] (internal: saga_motion_step hands the hand normals to the distance operator and the palm-marker normals to the
+// term operator, each contiguous, from ONE staging of the mesh)
+int saga_vertex_normals_window_split(const saga_model_t* m, const float* verts, const int32_t* sel, int n_a, int n_b, float* normals_a,
+                                     float* normals_b, int S, int T, int t0, void* stream) {
+    SAGA_CHECK_ARG(sel && n_a > 0 && n_b > 0 && normals_b, "saga_vertex_normals_window_split: bad arguments");
+    SAGA_CHECK_ARG(S >= 0 && T > 0 && t0 >= 0 && t0 < T, "saga_vertex_normals_window_split: bad sizes S=%d T=%d t0=%d", S, T, t0);
+    return launch(m, verts, sel, n_a + n_b, normals_a, S * (T - t0), T, t0, stream, n_a, normals_b);
 }
 
 // ---- the loss kernel's reads of the mesh, served once per candidate from LDS (saga_fit_step) --------------------------------

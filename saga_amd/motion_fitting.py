@@ -601,10 +601,10 @@ class FittingOP:
         mask[49:49 + 6] = 0
         mask[33:33 + 6] = 0
         mask[69:] = 0
-        keep.update(mask=mask, hand_sel=rh_rows.to(torch.int32).contiguous(), palm_sel=mk_rows[-22:].to(torch.int32).contiguous())
+        keep.update(mask=mask, normal_sel=torch.cat([rh_rows, mk_rows[-22:]]).to(torch.int32).contiguous())
         P = _lib.ptr
         tabs = pk.rows.tables(dev)
-        tables = _lib.MotionTables(hand_normal_sel=P(keep['hand_sel']), palm_normal_sel=P(keep['palm_sel']), marker_mask=P(mask))
+        tables = _lib.MotionTables(normal_sel=P(keep['normal_sel']), marker_mask=P(mask))
         for k, (tb, n, t0) in enumerate(zip(tabs, pk.rows.sizes, pk.rows.t0)):
             tables.sets[k] = _lib.PickSet(pos=P(tb[0]), inv_ptr=P(tb[1]), inv_idx=P(tb[2]), n=n, t0=t0)
         prob = _lib.MotionProblem(**{k: P(keep[k]) for k in ('markers_rec', 'markers_end', 'contact_lbl', 'contact_object',
