@@ -239,6 +239,9 @@ extern "C" int saga_debug_read_phases(unsigned long long* out) {
 // tile live in LDS in their own centred frames as (-2x,-2y,-2z,|p|^2); the approximate pass costs 3 fmas per pair, the
 // exact pass re-evaluates the two candidate chunks of every query with the arithmetic of nn_scan.h.
 #define GLF_NO 4                // object points per lane and pass, object -> hand
+#ifndef GL_PAIR_XY
+#define GL_PAIR_XY true         // hand / marker -> object scan (64 object tiles): one sorted insert per TWO matrix tiles (nn_fast.h, PAIR)
+#endif
 #define GL_OPL (GL_TILE / GL_THREADS)   // object points per lane of the fast kernel (8)
 #ifndef GL_NRM_FPS
 #define GL_NRM_FPS 2             // faces per vertex and gather step of the hand normals (3: 1.22 ms against 1.10, registers)
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
                 for (int t = r + wave; t < r1; t += GL_THREADS / 64)
                     reinterpret_cast<nn_h8*>(sImgO)[(t - r) * 64 + lane] = nnf_build_A(sObj, Opad, t, lane, ko);
                 __syncthreads();
-                nnf_mfma_tiles<GL_NQ, true, true>(st, sImgO, Opad / NNF_CH, r, r1, r, ko, act);
+                nnf_mfma_tiles<GL_NQ, true, true, GL_PAIR_XY>(st, sImgO, Opad / NNF_CH, r, r1, r, ko, act);
             }
 #endif
             nnf_mfma_end<GL_NQ>(st, ko, m1, m2, m3, c1, c2);
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
         }
 #pragma unroll
         for (int i = 0; i < GL_NSUM; ++i) sums[i] = 0.f;
-        nnf_resolve<GL_NQ, true>(sObj, Opad / NNF_CH, fo, 0, cx, cy, cz, qx, qy, qz, m1, m2, m3, c1, c2, best, bi);
+        nnf_resolve<GL_NQ, true, false, GL_PAIR_XY>(sObj, Opad / NNF_CH, fo, 0, cx, cy, cz, qx, qy, qz, m1, m2, m3, c1, c2, best, bi);
         GL_T(3);
 #pragma unroll
         for (int i = 0; i < GL_NQ; ++i) {

@@ -317,12 +317,65 @@ __device__ __forceinline__ void nnf_mfma_begin(NnfMfmaState<NQ>& st, const NnfSc
         }
 }
 
-template <int NQ, bool IMAGE, bool EVEN>
+// PAIR: two consecutive tiles (2k, 2k+1; tile_lo even) share one sorted insert -- the unit the triples rank is then the "pair
+// chunk" 2k + (lane>>5) = chunks {4k + h, 4k + 2 + h} (32 points), half as many inserts per matrix instruction, and the exact
+// pass re-evaluates up to four 16-point chunks instead of two (nnf_resolve<.., PAIR>).  Pays for long scans (the 64 object tiles
+// of the fused loss kernel), not for short ones.
+template <int NQ, bool IMAGE, bool EVEN, bool PAIR = false>
 __device__ __forceinline__ void nnf_mfma_tiles(NnfMfmaState<NQ>& st, const float* __restrict__ s, int n_chunks, int tile_lo, int tile_hi,
                                                int img_tile0, const NnfScales& k, unsigned act) {
     const int lane = __lane_id(), h = lane >> 5;
     const int n_pts = n_chunks * NNF_CH;
     const nn_f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (PAIR) {
+        auto tile_min = [&](const nn_f16v& D, float m) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) m = __builtin_elementwise_minimum(__builtin_elementwise_minimum(m, D[r]), D[r + 1]);
+            return m;
+        };
+        for (int tile = tile_lo; tile < tile_hi; tile += 2) {
+            const bool has2 = tile + 1 < tile_hi;                        // (wave-uniform)
+            const int tb = has2 ? tile + 1 : tile;
+            const nn_h8 A0 = IMAGE ? reinterpret_cast<const nn_h8*>(s)[(tile - img_tile0) * 64 + lane] : nnf_build_A(s, n_pts, tile, lane, k);
+            const nn_h8 A1 = IMAGE ? reinterpret_cast<const nn_h8*>(s)[(tb - img_tile0) * 64 + lane] : nnf_build_A(s, n_pts, tb, lane, k);
+            const int c = tile + h;                                       // pair chunk 2 (tile / 2) + h
+            const bool v0 = EVEN || 2 * tile + h < n_chunks, v1 = has2 && (EVEN || 2 * tile + 2 + h < n_chunks);
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const bool a0 = (act >> (2 * i)) & 1u, a1 = (act >> (2 * i + 1)) & 1u;
+                if (a0 && a1) {
+                    float ma = INFINITY, mb = INFINITY;
+                    {
+                        const nn_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, st.Bq[i][0], zero16, 0, 0, 0);
+                        const nn_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, st.Bq[i][1], zero16, 0, 0, 0);
+                        ma = tile_min(D0, ma); mb = tile_min(D1, mb);
+                        if (!EVEN) { ma = v0 ? ma : INFINITY; mb = v0 ? mb : INFINITY; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (has2) {
+                        const nn_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, st.Bq[i][0], zero16, 0, 0, 0);
+                        const nn_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, st.Bq[i][1], zero16, 0, 0, 0);
+                        const float na = tile_min(D0, ma), nb = tile_min(D1, mb);
+                        ma = (EVEN || v1) ? na : ma; mb = (EVEN || v1) ? nb : mb;
+                    }
+                    nnf_insert3(ma, c, st.M1[i][0], st.M2[i][0], st.M3[i][0], st.C1[i][0], st.C2[i][0]);
+                    nnf_insert3(mb, c, st.M1[i][1], st.M2[i][1], st.M3[i][1], st.C1[i][1], st.C2[i][1]);
+                } else if (a0 || a1) {
+                    const nn_h8 Bq = a0 ? st.Bq[i][0] : st.Bq[i][1];
+                    float ma = tile_min(__builtin_amdgcn_mfma_f32_32x32x16_f16(A0, Bq, zero16, 0, 0, 0), INFINITY);
+                    if (!EVEN) ma = v0 ? ma : INFINITY;
+                    if (has2) {
+                        const float na = tile_min(__builtin_amdgcn_mfma_f32_32x32x16_f16(A1, Bq, zero16, 0, 0, 0), ma);
+                        ma = (EVEN || v1) ? na : ma;
+                    }
+                    if (a0) nnf_insert3(ma, c, st.M1[i][0], st.M2[i][0], st.M3[i][0], st.C1[i][0], st.C2[i][0]);
+                    else nnf_insert3(ma, c, st.M1[i][1], st.M2[i][1], st.M3[i][1], st.C1[i][1], st.C2[i][1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
+    }
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
         const nn_h8 A = IMAGE ? reinterpret_cast<const nn_h8*>(s)[(tile - img_tile0) * 64 + lane] : nnf_build_A(s, n_pts, tile, lane, k);
         const int c = 2 * tile + h;
@@ -439,7 +492,8 @@ __device__ __forceinline__ void nnf_exact_chunk(const float* __restrict__ s, con
 // (global index of point 0 of this tile = base; tiles must come in index order).  Every lane of the wave must call it
 // together (the slow path is a wave-wide loop).
 // MFMA_PASS: the chunk minima come from nnf_scan_mfma (its error bound replaces the vector pass's).
-template <int NQ, bool MFMA_PASS = false, bool ORIG = false>
+// PAIR: c1 / c2 are pair chunks of nnf_mfma_tiles<.., PAIR> (pair chunk c = chunks 4 (c>>1) + (c&1) and that + 2).
+template <int NQ, bool MFMA_PASS = false, bool ORIG = false, bool PAIR = false>
 __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_chunks, const NnfFrame f, int base,
                                             const float (&qx)[NQ], const float (&qy)[NQ], const float (&qz)[NQ],
                                             const float (&ox)[NQ], const float (&oy)[NQ], const float (&oz)[NQ],
@@ -464,8 +518,22 @@ __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_c
             const bool two = c2[i] >= 0 && m2[i] <= thr;
             const int a = two ? min(c1[i], c2[i]) : c1[i];
             const int b = two ? max(c1[i], c2[i]) : c1[i];
-            nnf_exact_chunk<ORIG>(s, f, a, base, ox[i], oy[i], oz[i], best[i], bi[i], sorig);
-            if (b != a) nnf_exact_chunk<ORIG>(s, f, b, base, ox[i], oy[i], oz[i], best[i], bi[i], sorig);
+            if (PAIR) {
+                // up to four 16-point chunks, ascending: pair chunks of different tile pairs do not interleave, the two of one
+                // tile pair (a = 2k, b = 2k + 1) are chunks 4k, 4k+2 and 4k+1, 4k+3
+                const int e0 = 4 * (a >> 1) + (a & 1), e3 = 4 * (b >> 1) + (b & 1) + 2;
+                const bool same = b != a && (a >> 1) == (b >> 1);
+                const int e1 = same ? e0 + 1 : e0 + 2, e2 = same ? e0 + 2 : e3 - 2;
+                nnf_exact_chunk<ORIG>(s, f, e0, base, ox[i], oy[i], oz[i], best[i], bi[i], sorig);
+                if (e1 < n_chunks) nnf_exact_chunk<ORIG>(s, f, e1, base, ox[i], oy[i], oz[i], best[i], bi[i], sorig);
+                if (b != a) {
+                    if (e2 < n_chunks) nnf_exact_chunk<ORIG>(s, f, e2, base, ox[i], oy[i], oz[i], best[i], bi[i], sorig);
+                    if (e3 < n_chunks) nnf_exact_chunk<ORIG>(s, f, e3, base, ox[i], oy[i], oz[i], best[i], bi[i], sorig);
+                }
+            } else {
+                nnf_exact_chunk<ORIG>(s, f, a, base, ox[i], oy[i], oz[i], best[i], bi[i], sorig);
+                if (b != a) nnf_exact_chunk<ORIG>(s, f, b, base, ox[i], oy[i], oz[i], best[i], bi[i], sorig);
+            }
         }
         // slow path (three or more chunks inside the margin), one query at a time with the whole wave: lane l takes
         // chunks l, l+64, ..., re-evaluates those whose approximate minimum is inside the margin exactly (ascending, strict

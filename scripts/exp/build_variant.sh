@@ -9,7 +9,7 @@ mkdir -p $OUT $OBJ
 # the experiment switches only compile in an experiment build, whose saga_version() is negative: load with SAGA_ALLOW_EXPERIMENT_LIB=1
 EXP=""; case "$*" in *_EXP_*|*GL_PHASE_TIMING*) EXP="-DSAGA_EXPERIMENT_BUILD";; esac
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=fast-honor-pragmas $EXP $*"
-for f in model pose blend_gemm skin chamfer normals smplx_api grasp_loss rot6d fit_step rows motion_terms; do
+for f in model pose blend_gemm skin chamfer normals smplx_api grasp_loss rot6d fit_step rows motion_terms motion_step; do
   X=""; [ $f = blend_gemm ] && X="-mllvm -amdgpu-mfma-vgpr-form=1"      # as the Makefile
   /opt/rocm/bin/hipcc $FLAGS $X -c $f.hip -o $OBJ/$f.o &
 done

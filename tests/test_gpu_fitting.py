@@ -697,3 +697,36 @@ def test_fused_loss_beyond_one_object_tile(body_model_dir, O):
     for k in ('hand_pose', 'eye_pose'):
         a, b_ = _lib.VAR_SLICES[k]
         assert rel_err(grad[:, a:b_], getattr(op, k).grad.cpu().numpy()) < 1e-3, k
+
+
+@pytest.mark.parametrize('O', [37, 70, 96, 1000, 1503, 2048])
+def test_fused_loss_neighbours_with_ties_across_pair_chunks(body_model_dir, O):
+    """The fused kernel's hand / marker -> object scan ranks PAIRS of matrix tiles (nn_fast.h, PAIR: pair chunk = two 16-point
+    chunks 32 points apart) and its exact pass walks up to four chunks in ascending order.  Object clouds with exact duplicates
+    16, 32 and 48 points apart (ties inside a pair chunk, between the two pair chunks of one tile pair, and across tile pairs),
+    whole, odd and ragged tile counts: every neighbour index equals the stand-alone ChamferDistance's (lowest index wins), both
+    directions, and the signed distances follow."""
+    from saga_amd.chamfer_distance import ChamferDistance
+    from saga_amd.grasp_loss import grasp_loss_terms
+    B = 4
+    op, vp, idx, var_np, d = _setup(body_model_dir, B, n_points=O)
+    op.bm = op.bm_male
+    op.set_variables(var_np)
+    _immerse_object(op, d, B)
+    vo, no, oc = d['verts_o'][:, :O].copy(), d['normals_o'][:, :O].copy(), d['oc'].reshape(B, -1)[:, :O].copy()
+    for j in range(0, O - 52, 64):
+        for dst, src in ((j + 17, j + 1), (j + 34, j + 2), (j + 51, j + 3), (j + 20, j + 52 if j + 52 < O else j + 4), (j + 37, j + 21)):
+            vo[:, dst] = vo[:, src]
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    with torch.no_grad():
+        verts = op.bm(return_verts=True, **op.body_params()).vertices
+        r = grasp_loss_terms(verts, op.bm, op.tables, cu(vo), cu(no), cu(d['markers']), cu(d['mc']), cu(oc))
+        d1, _, i_h2o, i_o2h = ChamferDistance(verts[:, op.rhand_verts].contiguous(), cu(vo))
+        _, _, i_m2o, _ = ChamferDistance(verts[:, op.markers_143].contiguous(), cu(vo))
+    assert torch.equal(r['idx_h2o'], i_h2o) and torch.equal(r['idx_o2h'], i_o2h) and torch.equal(r['idx_m2o'], i_m2o)
+    np.testing.assert_allclose(r['h2o_signed'].abs().cpu().numpy(), d1.sqrt().cpu().numpy(), rtol=1e-6, atol=1e-9)
+    if O >= 70:      # the duplicates are in play: some query's neighbour is a point that has a copy at a higher index
+        dup_src = torch.zeros(O, dtype=torch.bool)
+        for j in range(0, O - 52, 64):
+            dup_src[[j + 1, j + 2, j + 3, j + 21]] = True
+        assert dup_src.cuda()[i_h2o.long()].any() or dup_src.cuda()[i_m2o.long()].any()
