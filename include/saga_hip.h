@@ -195,6 +195,13 @@ int saga_chamfer_bwd(const float* x, const float* y, const int32_t* idx1, const 
 int saga_p2p_signed_fwd(const float* x, const float* y, const float* x_normals, const float* y_normals,
                         float* y2x_signed, float* x2y_signed, int32_t* yidx, int32_t* xidx, float* y2x_vec, float* x2y_vec,
                         int N, int P1, int P2, void* stream);
+/* The same forward for LARGE clouds (WholeGraspPose/trainer.py:280-281 measures body meshes against object / scene clouds): with
+ * ws = saga_chamfer_workspace_bytes(N, P1, P2) bytes of device workspace a direction whose database cloud has >= 4,096 points is
+ * searched with the pruned search of saga_chamfer_fwd_ws -- same indices, hence the same outputs bit for bit.  ws NULL: the call
+ * above. */
+int saga_p2p_signed_fwd_ws(const float* x, const float* y, const float* x_normals, const float* y_normals,
+                           float* y2x_signed, float* x2y_signed, int32_t* yidx, int32_t* xidx, float* y2x_vec, float* x2y_vec,
+                           int N, int P1, int P2, void* ws, size_t ws_bytes, void* stream);
 int saga_p2p_signed_bwd(const float* x, const float* y, const int32_t* yidx, const int32_t* xidx,
                         const float* y2x_signed, const float* x2y_signed,
                         const float* g_y2x_signed, const float* g_x2y_signed, const float* g_y2x_vec, const float* g_x2y_vec,

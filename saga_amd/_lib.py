@@ -152,6 +152,8 @@ PROTOTYPES = {
                                         c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
     'saga_p2p_signed_fwd': (ctypes.c_int, [c_float_p] * 6 + [c_int_p, c_int_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, c_stream]),
+    'saga_p2p_signed_fwd_ws': (ctypes.c_int, [c_float_p] * 6 + [c_int_p, c_int_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, c_stream]),
     'saga_p2p_signed_bwd': (ctypes.c_int, [c_float_p, c_float_p, c_int_p, c_int_p] + [c_float_p] * 8 + [ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, c_stream]),
     'saga_pick_sets_fwd': (ctypes.c_int, [c_float_p, ctypes.POINTER(PickSet), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),

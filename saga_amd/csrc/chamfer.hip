@@ -346,6 +346,15 @@ __global__ void p2p_signed_kernel(const float* __restrict__ a, const float* __re
 extern "C" int saga_p2p_signed_fwd(const float* x, const float* y, const float* x_normals, const float* y_normals, float* y2x_signed,
                                    float* x2y_signed, int32_t* yidx, int32_t* xidx, float* y2x_vec, float* x2y_vec, int N, int P1, int P2,
                                    void* stream) {
+    return saga_p2p_signed_fwd_ws(x, y, x_normals, y_normals, y2x_signed, x2y_signed, yidx, xidx, y2x_vec, x2y_vec, N, P1, P2, nullptr, 0,
+                                  stream);
+}
+
+// ws: NULL, or saga_chamfer_workspace_bytes(N, P1, P2) bytes -- a direction whose database cloud is large is then searched with the
+// pruned search of saga_chamfer_fwd_ws (same indices, bit for bit)
+extern "C" int saga_p2p_signed_fwd_ws(const float* x, const float* y, const float* x_normals, const float* y_normals, float* y2x_signed,
+                                      float* x2y_signed, int32_t* yidx, int32_t* xidx, float* y2x_vec, float* x2y_vec, int N, int P1,
+                                      int P2, void* ws, size_t ws_bytes, void* stream) {
     SAGA_CHECK_ARG(N >= 0 && P1 >= 0 && P2 >= 0, "saga_p2p_signed_fwd: negative size");
     if (N == 0 || (P1 == 0 && P2 == 0)) return 0;
     SAGA_CHECK_ARG(P1 > 0 && P2 > 0, "saga_p2p_signed_fwd: empty cloud (P1=%d, P2=%d) has no nearest neighbour", P1, P2);
@@ -361,11 +370,16 @@ extern "C" int saga_p2p_signed_fwd(const float* x, const float* y, const float* 
                    "saga_p2p_signed_fwd: x2y_signed, xidx (and x2y_vec) are given together or all NULL");
     SAGA_CHECK_ARG(N <= 65535, "saga_p2p_signed_fwd: batch %d exceeds 65535", N);
     hipStream_t st = (hipStream_t)stream;
-    void* prof = saga_prof_begin(SAGA_PROF_CHAMFER, stream);
     int rc = 0;
-    if (do_x2y) rc = launch_scan(x, y, nullptr, xidx, N, P1, P2, st);
-    if (!rc && do_y2x) rc = launch_scan(y, x, nullptr, yidx, N, P2, P1, st);
-    saga_prof_end(prof);
+    if (ws && nnp_layout(N, P1, P2).total) {
+        // (indices only: idx1 = x -> y, idx2 = y -> x; a NULL pair skips that direction)
+        rc = saga_chamfer_fwd_ws(x, y, nullptr, nullptr, do_x2y ? xidx : nullptr, do_y2x ? yidx : nullptr, N, P1, P2, ws, ws_bytes, stream);
+    } else {
+        void* prof = saga_prof_begin(SAGA_PROF_CHAMFER, stream);
+        if (do_x2y) rc = launch_scan(x, y, nullptr, xidx, N, P1, P2, st);
+        if (!rc && do_y2x) rc = launch_scan(y, x, nullptr, yidx, N, P2, P1, st);
+        saga_prof_end(prof);
+    }
     if (rc) return rc;
     // x2y = x - y[xidx], signed by y_normals[xidx] (:76-81); y2x = y - x[yidx], signed by x_normals[yidx] (:68-74)
     if (do_x2y) {

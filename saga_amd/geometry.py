@@ -28,8 +28,11 @@ class _P2PSigned(torch.autograd.Function):
         y2x_v = torch.empty(N, P2, 3, **f32) if (want_vec and do_y2x) else None
         x2y_v = torch.empty(N, P1, 3, **f32) if (want_vec and do_x2y) else None
         P = _lib.ptr
-        _lib.call('saga_p2p_signed_fwd', xc.device, P(xc), P(yc), P(xn), P(yn), P(y2x_s), P(x2y_s), P(yidx), P(xidx), P(y2x_v),
-                  P(x2y_v), N, P1, P2)
+        # large clouds: the pruned search, with a workspace allocated here (same indices as the scan, bit for bit)
+        nbytes = _lib.load().saga_chamfer_workspace_bytes(N, P1, P2) if N > 0 and P1 > 0 and P2 > 0 else 0
+        ws = torch.empty(nbytes, device=xc.device, dtype=torch.uint8) if nbytes else None
+        _lib.call('saga_p2p_signed_fwd_ws', xc.device, P(xc), P(yc), P(xn), P(yn), P(y2x_s), P(x2y_s), P(yidx), P(xidx), P(y2x_v),
+                  P(x2y_v), N, P1, P2, P(ws), nbytes)
         ctx.save_for_backward(xc, yc, yidx, xidx, y2x_s, x2y_s)
         ctx.mark_non_differentiable(*[t for t in (yidx, xidx) if t is not None])
         ctx.set_materialize_grads(False)

@@ -217,6 +217,45 @@ def test_chamfer_workspace_entry_point_through_the_c_abi():
     assert torch.equal(no_ws, ref[2])
 
 
+@pytest.mark.parametrize('directions', ['both', 'x2y', 'y2x'])
+def test_p2p_signed_large_clouds_take_the_pruned_search(directions):
+    """point2point_signed on clouds large enough for the pruned search (saga_p2p_signed_fwd_ws; reference call shape
+    WholeGraspPose/trainer.py:280-281: a body mesh against a large object cloud): every output equals the scan path's
+    (SAGA_NN_PRUNE=0) bit for bit -- signed distances, indices, vectors -- for both directions and for one direction alone, and
+    the backward (which reads the indices) gives the same gradients."""
+    import os
+    from saga_amd.geometry import point2point_signed
+    g = torch.Generator().manual_seed(21)
+    N, P1, P2 = 2, 5000, 6000
+    x = (torch.randn(N, P1, 3, generator=g) * torch.tensor([0.3, 0.15, 0.8])).cuda()
+    y = (torch.randn(N, P2, 3, generator=g) * 0.3).cuda()
+    y[:, 100:200] = y[:, 3000:3100]                                    # duplicates: exact ties, the lowest index must win
+    xn = torch.nn.functional.normalize(torch.randn(N, P1, 3, generator=g), dim=-1).cuda()
+    yn = torch.nn.functional.normalize(torch.randn(N, P2, 3, generator=g), dim=-1).cuda()
+    wy, wx = torch.randn(N, P2, generator=g).cuda(), torch.randn(N, P1, generator=g).cuda()
+    res = {}
+    for mode in ('pruned', 'scan'):
+        if mode == 'scan':
+            os.environ['SAGA_NN_PRUNE'] = '0'
+        try:
+            xx, yy = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+            out = point2point_signed(xx, yy, xn, yn, return_vector=True, directions=directions)
+            loss = sum((o * w).sum() for o, w in zip(out[:2], (wy, wx)) if o is not None)
+            loss = loss + sum((o ** 2).sum() for o in out[4:] if o is not None)
+            loss.backward()
+            res[mode] = [o.detach() if o is not None else None for o in out] + [xx.grad, yy.grad]
+        finally:
+            os.environ.pop('SAGA_NN_PRUNE', None)
+    for a, b in zip(res['pruned'], res['scan']):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+    y2x, x2y, yidx, xidx = res['pruned'][:4]
+    assert (y2x is None) == (directions == 'x2y') and (x2y is None) == (directions == 'y2x')
+    if xidx is not None:
+        assert not ((xidx >= 3000) & (xidx < 3100)).any()                # a duplicate at the higher index never wins its tie
+
+
 def test_chamfer_both_call_forms_and_errors():
     import saga_amd.chamfer_distance as chd
     x = torch.randn(1, 5, 3).cuda()
