@@ -348,6 +348,11 @@ class FittingOP:
 
     # ---- stage 2 -------------------------------------------------------------------------------------------------------
     def _make_picker(self, rhand_verts):
+        key = bytes(np.asarray(rhand_verts.detach().cpu() if torch.is_tensor(rhand_verts) else rhand_verts, dtype=np.int64).data)
+        if self._picker is not None and self.__dict__.get('_picker_key') == (key, self.start_t, bool(self.sparse_backward),
+                                                                              bool(self.reduced_forward), self.body_smooth_loss is None):
+            return                                  # same hand, same switches: the tables and the loss-vertex model stand
+        self._picker_key = (key, self.start_t, bool(self.sparse_backward), bool(self.reduced_forward), self.body_smooth_loss is None)
         sets = {'markers': self.markers_ids, 'markers_143': self.markers_ids_143, 'rhand': rhand_verts}
         sets.update(self.foot_groups)
         # (the objective reads the 143 markers and the hand on the frames start_t.. only: picked as windows; the sets stay in

@@ -14,7 +14,7 @@ from saga_amd.synthetic import make_object_cloud, write_body_model
 ap = argparse.ArgumentParser()
 ap.add_argument('--sequences', type=int, default=256)
 ap.add_argument('--frames', type=int, default=61)
-ap.add_argument('--iters', type=int, default=5)
+ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--warmup', type=int, default=2)
 ap.add_argument('--dense-backward', action='store_true', help='dense [S*T,V,3] vertex gradient (the form the reference has)')
 ap.add_argument('--full-forward', action='store_true', help='evaluate the whole mesh in the forward (reduced_forward=False)')

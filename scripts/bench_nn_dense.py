@@ -26,7 +26,7 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.iters
 pairs = 2.0 * a.batch * a.verts * a.points
 res = {'config': 'full-mesh chamfer %d x %d, B=%d' % (a.verts, a.points, a.batch), 'ms': round(dt * 1e3, 2),
-       'pairs_per_s': pairs / dt, 'valu_tflops_8flop_per_pair': round(pairs * 8 / dt / 1e12, 2), 'peak_tflops': 157.3}
+       'pairs_per_s': pairs / dt, 'equivalent_scan_tflops_8flop_per_pair': round(pairs * 8 / dt / 1e12, 2), 'peak_tflops': 157.3}
 if a.check:
     os.environ['SAGA_NN_EXACT_SCAN'] = '1'
     ref = chd.ChamferDistance(x[:8], y[:8])

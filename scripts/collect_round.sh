@@ -15,3 +15,6 @@ run config4_motion_mesh_like python3 scripts/bench_motion.py --mesh-faces
 run config4_motion_full_forward python3 scripts/bench_motion.py --full-forward
 run config4_motion_whole_fit python3 scripts/bench_motion.py --whole-fit
 run whole_fit python3 scripts/bench_fit.py
+run config4_motion_autograd python3 scripts/bench_motion.py --autograd
+run config4_motion_1x61 python3 scripts/bench_motion.py --sequences 1 --iters 200
+run config5_dense_chamfer python3 scripts/bench_nn_dense.py --check
