@@ -244,9 +244,9 @@ extern "C" int saga_debug_nnp_stats(unsigned long long* out, int reset) {
 // (accumulated in registers, one atomic per counter and wave at the end: atomics inside the loop would be what is measured)
 #define NNP_STAT(i, v) do { st_acc[i] += (unsigned long long)(v); } while (0)
 #define NNP_CLK(i) do { const unsigned long long t_ = clock64(); st_acc[i] += t_ - t_prev; t_prev = t_; } while (0)
-#define NNP_CLK0() unsigned long long t_prev = clock64(); const unsigned long long t_start = t_prev
+#define NNP_CLK0() unsigned long long t_prev = clock64(); const unsigned long long t_begin_ = t_prev
 #define NNP_STAT_DECL() unsigned long long st_acc[16] = {0}
-#define NNP_CLK_END() do { st_acc[13] = clock64() - t_start; if (lane == 0) { for (int i_ = 0; i_ < 14; ++i_) if (st_acc[i_]) atomicAdd(&nnp_stats[i_], st_acc[i_]); \
+#define NNP_CLK_END() do { st_acc[13] = clock64() - t_begin_; if (lane == 0) { for (int i_ = 0; i_ < 14; ++i_) if (st_acc[i_]) atomicAdd(&nnp_stats[i_], st_acc[i_]); \
     atomicMax(&nnp_stats[14], st_acc[13]); if (st_acc[13] > 4 * 1000000ull) atomicAdd(&nnp_stats[15], 1ull); } } while (0)
 #else
 #define NNP_STAT(i, v)
