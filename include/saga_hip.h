@@ -320,6 +320,9 @@ typedef struct {
     const int32_t* ring_ids;
     const int32_t* hand_tri_ptr;
     const int32_t* hand_tri;
+    /* Optional (NULL: the kernels evaluate the power themselves): hand_prior_w [n_hand] = hand_weights where
+     * hand_weights^(1/2.5) > 0.7 (the vertex mask of the prior-contact term, fittingop.py:195), else 0 -- a constant of the table */
+    const float* hand_prior_w;
 } saga_grasp_tables_t;
 
 int saga_grasp_loss_fwd(const saga_model_t* m, const saga_grasp_tables_t* tables, const float* verts,

@@ -43,7 +43,7 @@ class GraspTables(ctypes.Structure):
                 ('hand_weights', ctypes.c_void_p), ('unique_ids', ctypes.c_void_p), ('marker_slot', ctypes.c_void_p),
                 ('hand_slot', ctypes.c_void_p), ('foot_slot', ctypes.c_void_p),
                 ('n_ring', ctypes.c_int32), ('ring_ids', ctypes.c_void_p),
-                ('hand_tri_ptr', ctypes.c_void_p), ('hand_tri', ctypes.c_void_p)]
+                ('hand_tri_ptr', ctypes.c_void_p), ('hand_tri', ctypes.c_void_p), ('hand_prior_w', ctypes.c_void_p)]
 
 
 class PickSet(ctypes.Structure):

@@ -52,6 +52,15 @@ __device__ __forceinline__ float gl_wave_sum_lane0(float v) {
     return v;
 }
 
+// prior-contact weight of hand vertex i (fittingop.py:195,199): rhand_weight where rhand_weight^(1/2.5) > 0.7, else 0.  The mask
+// depends on the table only: the host precomputes it (tables' hand_prior_w) when no entry sits within rounding of the threshold;
+// tables without it evaluate the power here.
+__device__ __forceinline__ float gl_prior_weight(const saga_grasp_tables_t& tb, int i) {
+    if (tb.hand_prior_w) return tb.hand_prior_w[i];
+    const float vw = tb.hand_weights[i];
+    return powf(vw, 1.0f / 2.5f) > 0.7f ? vw : 0.f;
+}
+
 __global__ __launch_bounds__(GL_THREADS) void grasp_loss_fwd_kernel(
     saga_grasp_tables_t tb, const float* __restrict__ verts, const int32_t* __restrict__ vf_ptr,
     const int32_t* __restrict__ vf_tri, const float* __restrict__ obj,
@@ -137,9 +146,9 @@ __global__ __launch_bounds__(GL_THREADS) void grasp_loss_fwd_kernel(
                 const float d = dist * sgn(dot);
                 h2o_signed[(size_t)b * H + q] = d;
                 idx_h2o[(size_t)b * H + q] = k;
-                const float vw = tb.hand_weights[q];
-                const bool near = (d < 0.02f) && (d > 0.f) && (powf(vw, 1.0f / 2.5f) > 0.7f);   // fittingop.py:195
-                sums[5] += fabsf(d) * (near ? vw : 0.f);                                          // :199,210
+                const float pw = gl_prior_weight(tb, q);                                        // vw where vw^(1/2.5) > 0.7, else 0
+                const bool near = (d < 0.02f) && (d > 0.f);                                      // fittingop.py:195
+                sums[5] += fabsf(d) * (near ? pw : 0.f);                                          // :199,210
                 sums[6] += fabsf(d) * (d < 0.f ? 10.f : 0.f);                                     // :200,211
                 sums[8] += d < 0.f ? 1.f : 0.f;
                 sums[10] += (d < 0.001f && d > -0.001f) ? 1.f : 0.f;
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
     constexpr int SM_OBJ = NNF_TILE_FLOATS(GL_TILE), SM_TOTAL = SM_OBJ + NNF_TILE_FLOATS(GL_MAX_HAND);
     __shared__ __attribute__((aligned(16))) float smem[SM_TOTAL];
     __shared__ float red[GL_THREADS / 64][GL_NSUM];
-    __shared__ float sbox[6 * (GL_THREADS / 64)];
+    __shared__ float sbox[18 * (GL_THREADS / 64)];
     float* const sObj = smem;
     float* const sImgO = smem + SM_OBJ;
     // candidates in reverse launch order: the producer (skinning) wrote them in ascending order, so the most recently
@@ -339,14 +348,21 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
         olo[1] = fminf(olo[1], op[i].y); ohi[1] = fmaxf(ohi[1], op[i].y);
         olo[2] = fminf(olo[2], op[i].z); ohi[2] = fmaxf(ohi[2], op[i].z);
     }
-    const NnfFrame fo = nnf_frame_from_box(olo, ohi, sbox, tid, GL_THREADS);
-    // the hand's frame, and the box of ALL queries (hand + markers) in the object's frame: one scale of the matrix-core pass for
-    // the whole block (nnf_scales' rq: any upper bound of the framed queries' largest |coordinate|), so its A operands can be shared
-    float qlo[3], qhi[3];
+    // the object's frame, the hand's frame, and the box of ALL queries (hand + markers): one scale of the matrix-core pass for the
+    // whole block (nnf_scales' rq: any upper bound of the framed queries' largest |coordinate|), so its A operands can be shared.
+    // The three boxes are reduced over the block together (one pair of barriers).
+    NnfFrame fr[3];
+    {
+        float blo[3][3], bhi[3][3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { qlo[a] = fminf(hlo[a], mlo[a]); qhi[a] = fmaxf(hhi[a], mhi[a]); }
-    const NnfFrame fh = nnf_frame_from_box(hlo, hhi, sbox, tid, GL_THREADS);
-    const NnfFrame fq = nnf_frame_from_box(qlo, qhi, sbox, tid, GL_THREADS);      // .rp >= half diagonal of the queries' box about (.cx,.cy,.cz)
+        for (int a = 0; a < 3; ++a) {
+            blo[0][a] = olo[a]; bhi[0][a] = ohi[a];
+            blo[1][a] = hlo[a]; bhi[1][a] = hhi[a];
+            blo[2][a] = fminf(hlo[a], mlo[a]); bhi[2][a] = fmaxf(hhi[a], mhi[a]);
+        }
+        nnf_frames_from_boxes<3>(blo, bhi, sbox, tid, GL_THREADS, fr);
+    }
+    const NnfFrame fo = fr[0], fh = fr[1], fq = fr[2];      // fq.rp >= half diagonal of the queries' box about (fq.cx, fq.cy, fq.cz)
     const int Opad = (O + 31) & ~31;
 #pragma unroll
     for (int i = 0; i < GL_OPL; ++i) {
@@ -429,9 +445,9 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
                 const float d = dist * sgn(dot);
                 h2o_signed[(size_t)b * H + q] = d;
                 idx_h2o[(size_t)b * H + q] = k;
-                const float vw = tb.hand_weights[q];
-                const bool near = (d < 0.02f) && (d > 0.f) && (powf(vw, 1.0f / 2.5f) > 0.7f);   // fittingop.py:195
-                sums[5] += fabsf(d) * (near ? vw : 0.f);                                          // :199,210
+                const float pw = gl_prior_weight(tb, q);                                        // vw where vw^(1/2.5) > 0.7, else 0
+                const bool near = (d < 0.02f) && (d > 0.f);                                      // fittingop.py:195
+                sums[5] += fabsf(d) * (near ? pw : 0.f);                                          // :199,210
                 sums[6] += fabsf(d) * (d < 0.f ? 10.f : 0.f);                                     // :200,211
                 sums[8] += d < 0.f ? 1.f : 0.f;
                 sums[10] += (d < 0.001f && d > -0.001f) ? 1.f : 0.f;
@@ -657,9 +673,9 @@ __global__ __launch_bounds__(GL_BWD_THREADS) void grasp_loss_bwd_kernel(
     // hand -> object: |d_h| weighted by the prior-contact / collision masks (masks carry no gradient)
     for (int p = tid; p < H; p += GL_BWD_THREADS) {
         const float d = h2o_signed[(size_t)b * H + p];
-        const float vw = tb.hand_weights[p];
-        const bool near = (d < 0.02f) && (d > 0.f) && (powf(vw, 1.0f / 2.5f) > 0.7f);
-        const float coef = (g_prior * (near ? vw : 0.f) + g_hcol * (d < 0.f ? 10.f : 0.f)) / (float)H;
+        const float pw = gl_prior_weight(tb, p);
+        const bool near = (d < 0.02f) && (d > 0.f);
+        const float coef = (g_prior * (near ? pw : 0.f) + g_hcol * (d < 0.f ? 10.f : 0.f)) / (float)H;
         // d|d|/dh = sign(d)^2 * unit(h - y): zero where the sign is zero
         if (coef != 0.f && d != 0.f) {
             const float* h = hand_rec + ((size_t)b * H + p) * 3;

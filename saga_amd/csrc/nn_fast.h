@@ -56,36 +56,63 @@ __device__ __forceinline__ float nnf_axis_centre(float lo, float hi) {
     return 0.f;
 }
 
-// Block-wide bounding box -> frame.  lo/hi: this thread's partial box (+INF/-INF when it holds no point).
-// sred: >= 6 * (nthreads/64) floats of LDS.  Contains barriers: every thread of the block calls it.
-__device__ __forceinline__ NnfFrame nnf_frame_from_box(float (&lo)[3], float (&hi)[3], float* sred, int tid, int nthreads) {
+// wave-wide minimum / maximum in every lane: five immediate swizzle patterns and one half-wave swap (no index registers, no LDS
+// traffic; min / max are exact, so the pattern does not matter for the result)
+#define NNF_SWZ(v, o) __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), ((o) << 10) | 0x1f))
+__device__ __forceinline__ float nnf_wave_min(float v) {
+    v = fminf(v, NNF_SWZ(v, 16)); v = fminf(v, NNF_SWZ(v, 8)); v = fminf(v, NNF_SWZ(v, 4)); v = fminf(v, NNF_SWZ(v, 2));
+    v = fminf(v, NNF_SWZ(v, 1));
+    const unsigned u = (unsigned)__float_as_int(v);
+    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // one of the two is the lane's own value, the other its partner's
+    return fminf(__int_as_float((int)sw[0]), __int_as_float((int)sw[1]));
+}
+__device__ __forceinline__ float nnf_wave_max(float v) {
+    v = fmaxf(v, NNF_SWZ(v, 16)); v = fmaxf(v, NNF_SWZ(v, 8)); v = fmaxf(v, NNF_SWZ(v, 4)); v = fmaxf(v, NNF_SWZ(v, 2));
+    v = fmaxf(v, NNF_SWZ(v, 1));
+    const unsigned u = (unsigned)__float_as_int(v);
+    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__int_as_float((int)sw[0]), __int_as_float((int)sw[1]));
+}
+
+// Block-wide bounding boxes -> frames, K boxes in one pass (two barriers for all of them).  lo/hi: this thread's partial boxes
+// (+INF/-INF when it holds no point).  sred: >= 6 * K * (nthreads/64) floats of LDS.  Contains barriers: every thread of the block calls it.
+template <int K>
+__device__ __forceinline__ void nnf_frames_from_boxes(float (&lo)[K][3], float (&hi)[K][3], float* sred, int tid, int nthreads,
+                                                      NnfFrame (&f)[K]) {
     const int wave = tid >> 6, lane = tid & 63, nw = nthreads >> 6;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        for (int o = 32; o > 0; o >>= 1) {
-            lo[k] = fminf(lo[k], __shfl_xor(lo[k], o, 64));
-            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o, 64));
-        }
-    }
+    for (int b = 0; b < K; ++b)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { lo[b][k] = nnf_wave_min(lo[b][k]); hi[b][k] = nnf_wave_max(hi[b][k]); }
     __syncthreads();                     // sred may still be read by an earlier call
     if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { sred[wave * 6 + k] = lo[k]; sred[wave * 6 + 3 + k] = hi[k]; }
+        for (int b = 0; b < K; ++b)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { sred[(wave * K + b) * 6 + k] = lo[b][k]; sred[(wave * K + b) * 6 + 3 + k] = hi[b][k]; }
     }
     __syncthreads();
-    float c[3], r2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        float l = sred[k], h = sred[3 + k];
-        for (int w = 1; w < nw; ++w) { l = fminf(l, sred[w * 6 + k]); h = fmaxf(h, sred[w * 6 + 3 + k]); }
-        c[k] = nnf_axis_centre(l, h);
-        const float r = fmaxf(h - c[k], c[k] - l);
-        r2 = fmaf(r, r, r2);
+    for (int b = 0; b < K; ++b) {
+        float c[3], r2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float l = sred[b * 6 + k], h = sred[b * 6 + 3 + k];
+            for (int w = 1; w < nw; ++w) { l = fminf(l, sred[(w * K + b) * 6 + k]); h = fmaxf(h, sred[(w * K + b) * 6 + 3 + k]); }
+            c[k] = nnf_axis_centre(l, h);
+            const float r = fmaxf(h - c[k], c[k] - l);
+            r2 = fmaf(r, r, r2);
+        }
+        f[b].cx = nnf_uniform(c[0]); f[b].cy = nnf_uniform(c[1]); f[b].cz = nnf_uniform(c[2]);
+        f[b].rp = nnf_uniform(sqrtf(r2) * 1.0001f);
     }
-    NnfFrame f;
-    f.cx = nnf_uniform(c[0]); f.cy = nnf_uniform(c[1]); f.cz = nnf_uniform(c[2]);
-    f.rp = nnf_uniform(sqrtf(r2) * 1.0001f);
-    return f;
+}
+
+__device__ __forceinline__ NnfFrame nnf_frame_from_box(float (&lo)[3], float (&hi)[3], float* sred, int tid, int nthreads) {
+    float l[1][3] = {{lo[0], lo[1], lo[2]}}, h[1][3] = {{hi[0], hi[1], hi[2]}};
+    NnfFrame f[1];
+    nnf_frames_from_boxes<1>(l, h, sred, tid, nthreads, f);
+    return f[0];
 }
 
 // bounding box of cnt points of a global cloud (thread tid of nthreads takes every nthreads-th point)

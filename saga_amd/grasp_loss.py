@@ -31,13 +31,21 @@ class GraspTables:
         self.hand_weights = torch.as_tensor(np.asarray(hand_weights), dtype=torch.float32, device=device).contiguous()
         self.n_markers, self.n_hand, self.n_foot, self.n_unique = len(markers), len(hand), len(foot), len(uniq)
         self.max_id = int(uniq.max())
+        # the prior-contact vertex mask (fittingop.py:195: rhand_weight ** (1 / 2.5) > 0.7) is a constant of the table: precomputed
+        # unless an entry sits so close to the threshold that the host's and the device's power could disagree
+        w32 = np.asarray(hand_weights, dtype=np.float32).reshape(-1)
+        pw = np.power(w32.astype(np.float64), 1.0 / 2.5)
+        self.hand_prior_w = None
+        if w32.size and np.abs(pw - 0.7).min() > 1e-5:
+            self.hand_prior_w = torch.as_tensor(np.where(pw > 0.7, w32, np.float32(0)).astype(np.float32), device=device).contiguous()
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         self._fields = dict(
             n_markers=self.n_markers, n_hand=self.n_hand, n_foot=self.n_foot,
             n_body_markers=min(n_body_markers, self.n_markers), n_unique=self.n_unique,
             marker_ids=p(self.marker_ids), hand_ids=p(self.hand_ids), foot_ids=p(self.foot_ids),
             hand_weights=p(self.hand_weights), unique_ids=p(self.unique_ids), marker_slot=p(self.marker_slot),
-            hand_slot=p(self.hand_slot), foot_slot=p(self.foot_slot))
+            hand_slot=p(self.hand_slot), foot_slot=p(self.foot_slot),
+            hand_prior_w=p(self.hand_prior_w) if self.hand_prior_w is not None else None)
         self.struct = _lib.GraspTables(**self._fields)
         self._hand_host, self._uniq_host, self._device = hand, uniq, device
         self._mesh_structs = {}
