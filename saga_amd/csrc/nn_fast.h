@@ -325,23 +325,28 @@ struct NnfMfmaState {
 template <int NQ>
 __device__ __forceinline__ void nnf_mfma_begin(NnfMfmaState<NQ>& st, const NnfScales& k, const float (&qx)[NQ], const float (&qy)[NQ],
                                                const float (&qz)[NQ]) {
-    const int lane = __lane_id(), col = lane & 31, h = lane >> 5;
+    const int lane = __lane_id(), h = lane >> 5;
     const float sq = k.sq;
-    // B operands: tile (i, hh) = query i of lanes hh*32 .. hh*32+31
+    // B operands: tile (i, hh) = query i of lanes hh*32 .. hh*32+31 -- every lane needs the query of lane (lane & 31) + 32 hh: its
+    // own and its half-wave partner's (one v_permlane32_swap per coordinate hands both halves what they need)
     const _Float16 one = (_Float16)1.f;
 #pragma unroll
-    for (int i = 0; i < NQ; ++i)
+    for (int i = 0; i < NQ; ++i) {
+        const auto sx = __builtin_amdgcn_permlane32_swap((unsigned)__float_as_int(qx[i]), (unsigned)__float_as_int(qx[i]), false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap((unsigned)__float_as_int(qy[i]), (unsigned)__float_as_int(qy[i]), false, false);
+        const auto sz = __builtin_amdgcn_permlane32_swap((unsigned)__float_as_int(qz[i]), (unsigned)__float_as_int(qz[i]), false, false);
+        // (swap(v, v): element 0 = the value of the lane's counterpart in the LOWER half, element 1 = in the UPPER half)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            const int src = hh * 32 + col;
             _Float16 xh, xl, yh, yl, zh, zl;
-            nnf_split16(__shfl(qx[i], src, 64) * sq, xh, xl);
-            nnf_split16(__shfl(qy[i], src, 64) * sq, yh, yl);
-            nnf_split16(__shfl(qz[i], src, 64) * sq, zh, zl);
+            nnf_split16(__int_as_float((int)sx[hh]) * sq, xh, xl);
+            nnf_split16(__int_as_float((int)sy[hh]) * sq, yh, yl);
+            nnf_split16(__int_as_float((int)sz[hh]) * sq, zh, zl);
             const nn_h8 lo = {xh, yh, zh, xl, yl, zl, xh, yh}, hi = {zh, one, one, one, xl, yl, zl, one};
             st.Bq[i][hh] = h ? hi : lo;
             st.M1[i][hh] = INFINITY; st.M2[i][hh] = INFINITY; st.M3[i][hh] = INFINITY; st.C1[i][hh] = -1; st.C2[i][hh] = -1;
         }
+    }
 }
 
 // PAIR: two consecutive tiles (2k, 2k+1; tile_lo even) share one sorted insert -- the unit the triples rank is then the "pair
