@@ -25,7 +25,7 @@ def short(name):
 
 dur = collections.defaultdict(list)
 for f in glob.glob(os.path.join(root, 'trace', '**', '*kernel_trace.csv'), recursive=True):
-    for r in csv.DictReader(open(f)):
+    for r in sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp'])):      # launch order
         k = short(r['Kernel_Name'])
         if k.startswith(OURS):
             k = '%s grid=%s' % (k, int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z']))
@@ -41,10 +41,13 @@ for f in glob.glob(os.path.join(root, 'pmc*', '**', '*counter_collection.csv'), 
         cnt['%s grid=%s' % (k, r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
 
 out = {}
-lines = ['== kernel trace: launches, mean us, total ms']
+# mean over EVERY launch of the command (set-up, warm-up and timed steps: the first launches run at ramping clocks) and the mean
+# over the last 10 launches in launch order (= the timed region of `--steps 10`: what bench.py's HIP events measure)
+lines = ['== kernel trace: launches, mean us (all), mean us (last 10 = timed steps), total ms']
 for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-    lines.append('%-64s %6d %10.1f %10.2f' % (k, len(v), sum(v) / len(v), sum(v) / 1e3))
-    out[k] = {'launches': len(v), 'mean_us': sum(v) / len(v)}
+    last = v[-10:]
+    lines.append('%-64s %6d %10.1f %10.1f %10.2f' % (k, len(v), sum(v) / len(v), sum(last) / len(last), sum(v) / 1e3))
+    out[k] = {'launches': len(v), 'mean_us': sum(v) / len(v), 'mean_us_last10': sum(last) / len(last)}
 lines.append('== PMC: mean per launch (+ derived: HBM bytes per the guide, MFMA / VALU utilisation)')
 for k in sorted(cnt):
     c = {n: sum(v) / len(v) for n, v in cnt[k].items()}
