@@ -244,6 +244,17 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
         fb[1][g] = fb[0][g] + HI_STG * STAGE_BYTES;
     }
 
+    // EPI 0 adds the bias as ONE MORE K-STEP on the matrix cores: operands (bias[col], 1) in the k = 0 lanes, (0, 0) in the k = 1
+    // lanes, so acc = fma(1, bias, acc) = acc + bias -- the same rounding as the vector add it replaces (bit-identical), and the
+    // epilogue shrinks to its stores: every vector instruction there is issued under the co-resident block's MFMA burst (~100
+    // cycles each: 64 bias adds + 8 quad loads per wave and tile were most of the epilogue).  The two operand words per lane are
+    // requested here, before the k-loop's first LDS-DMA: the oldest entries of vmcnt, back long before they are used.
+    constexpr bool MFMA_BIAS = EPI == 0 && TRS && !LEPI;
+    float bias_op[WT];
+    if (MFMA_BIAS && bias) {
+#pragma unroll
+        for (int nt = 0; nt < WT; ++nt) bias_op[nt] = bias[n0 + wn * 32 * WT + nt * 32 + l31];
+    }
     gemm_static_for<0, NST - 1>([&](auto sc) __attribute__((always_inline)) {
         constexpr int S = decltype(sc)::value;
         if (S < T) issue(sc, S * BKT * 4);
@@ -307,6 +318,15 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
         });
     }
 
+    if (MFMA_BIAS && bias) {
+        const float one = half ? 0.f : 1.f;
+#pragma unroll
+        for (int nt = 0; nt < WT; ++nt) {
+            const float bv = half ? 0.f : bias_op[nt];
+#pragma unroll
+            for (int mt = 0; mt < WT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, one, acc[mt][nt], 0, 0, 0);
+        }
+    }
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     GEMM_STAMP(3 + 6 * trace_i)
     float* Cz = C;
@@ -350,7 +370,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
         // store: stores count in vmcnt, so a load issued between them would make its wait drain every store before it.
         const int colw = n0 + wn * 32 * WT + 4 * half;
         float4 bq[WT][4];
-        if ((EPI == 0 || EPI == 2) && bias) {
+        if ((EPI == 0 || EPI == 2) && bias && !MFMA_BIAS) {
             const float* bp = bias + colw;
 #pragma unroll
             for (int nt = 0; nt < WT; ++nt)
@@ -383,7 +403,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float4 v = make_float4(acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]);
-                    if ((EPI == 0 || EPI == 2) && bias) {
+                    if ((EPI == 0 || EPI == 2) && bias && !MFMA_BIAS) {
                         const float4 bv = bq[nt][q];
                         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                     }
