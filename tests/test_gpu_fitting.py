@@ -756,3 +756,38 @@ def test_other_hand_pca_size_takes_the_autograd_path_and_matches_oracle(body_mod
     for k in params[-1]:
         np.testing.assert_allclose(params[-1][k].cpu().numpy(), p_ref[-1][k].numpy(), atol=5e-3, err_msg=k)
     assert (params[-1]['right_hand_pose'].abs() > 0).any()          # stage 3 moved the hand coefficients
+
+
+def test_prior_contact_mask_precomputed_equals_in_kernel_power(body_model_dir):
+    """The prior-contact vertex mask (rhand_weight ** (1 / 2.5) > 0.7, fittingop.py:195) is a table constant the host precomputes
+    (``hand_prior_w`` of saga_grasp_tables_t); tables without the field -- another binding, or weights within rounding of the threshold --
+    make the kernels evaluate the power themselves.  Both forms: every output and the vertex gradient bit-equal, forward kernels (one
+    object tile and more) and backward, with the prior term active."""
+    import copy
+    import ctypes
+    from saga_amd.grasp_loss import grasp_loss_terms
+    for O in (2048, 2049):
+        B = 3
+        op, vp, idx, var_np, d = _setup(body_model_dir, B, n_points=2048)
+        op.bm = op.bm_male
+        op.set_variables(var_np)
+        _immerse_object(op, d, B)
+        rep = lambda a: np.ascontiguousarray(np.concatenate([a] * 2, axis=1)[:, :O])
+        cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        vo, no, oc = cu(rep(d['verts_o'])), cu(rep(d['normals_o'])), cu(rep(d['oc'].reshape(B, -1)))
+        assert op.tables.hand_prior_w is not None and op.tables.struct.hand_prior_w
+        plain = copy.copy(op.tables)
+        plain.struct = type(op.tables.struct).from_buffer_copy(op.tables.struct)
+        plain.struct.hand_prior_w = None
+        with torch.no_grad():
+            verts0 = op.bm(return_verts=True, **op.body_params()).vertices
+        res = []
+        for tb in (op.tables, plain):
+            verts = verts0.clone().requires_grad_(True)
+            r = grasp_loss_terms(verts, op.bm, tb, vo, no, cu(d['markers']), cu(d['mc']), oc)
+            (r['terms'] * torch.arange(1, 17, device='cuda')).sum().backward()
+            res.append((r, verts.grad))
+        assert (res[0][0]['terms'][:, 5] > 0).all()                    # the prior-contact term is live
+        for k in res[0][0]:
+            assert torch.equal(res[0][0][k], res[1][0][k]), k
+        assert torch.equal(res[0][1], res[1][1]) and res[0][1].abs().max() > 0
