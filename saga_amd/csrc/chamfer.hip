@@ -90,8 +90,9 @@ const float* __restrict__ q, const float* __restrict__ db,
 #pragma unroll
         for (int i = 0; i < NQ; ++i) { qx[i] = ox[i] - f.cx; qy[i] = oy[i] - f.cy; qz[i] = oz[i] - f.cz; }
         __syncthreads();
+        float e_floor = 0.f;
         if (MF) {
-            nnf_scan_mfma<NQ>(sdb, cnt_pad / NNF_CH, f, qx, qy, qz, m1, m2, m3, c1, c2);
+            nnf_scan_mfma<NQ>(sdb, cnt_pad / NNF_CH, f, qx, qy, qz, m1, m2, m3, c1, c2, e_floor);
             // the framed queries are formed again (same subtraction, same bits) instead of staying live across the matrix-core pass
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
@@ -99,7 +100,7 @@ const float* __restrict__ q, const float* __restrict__ db,
                 qx[i] = ox[i] - f.cx; qy[i] = oy[i] - f.cy; qz[i] = oz[i] - f.cz;
             }
         } else nnf_scan<NQ>(sdb, cnt_pad / NNF_CH, qx, qy, qz, m1, m2, m3, c1, c2);
-        nnf_resolve<NQ, MF>(sdb, cnt_pad / NNF_CH, f, t0, qx, qy, qz, ox, oy, oz, m1, m2, m3, c1, c2, best, bi);
+        nnf_resolve<NQ, MF>(sdb, cnt_pad / NNF_CH, f, t0, qx, qy, qz, ox, oy, oz, m1, m2, m3, c1, c2, best, bi, nullptr, e_floor);
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {

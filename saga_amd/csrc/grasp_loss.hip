@@ -386,12 +386,14 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
         int c1[GL_NQ], c2[GL_NQ], bi[GL_NQ];
 #pragma unroll
         for (int i = 0; i < GL_NQ; ++i) { cx[i] = qx[i] - fo.cx; cy[i] = qy[i] - fo.cy; cz[i] = qz[i] - fo.cz; }
+        float ef_o;         // error floor of the object scan's scales (nn_fast.h)
         // approximate pass on the matrix cores (f16-split operands, nn_fast.h), exact pass on the two candidate chunks.  The four
         // waves scan the same 64 object tiles: their A operands are built ONCE per block, 16 tiles (16 KB) at a time, into the LDS
         // the hand tile will take afterwards (a wave rebuilding all of them itself spent a quarter of this scan's instructions there)
         {
             const float rq = fq.rp + fmaxf(fabsf(fq.cx - fo.cx), fmaxf(fabsf(fq.cy - fo.cy), fabsf(fq.cz - fo.cz)));
             const NnfScales ko = nnf_scales(fo.rp, rq);
+            ef_o = nnf_mfma_error_floor(fo, ko);
             // query tile (i, hh) of this wave starts at query wave*64 + hh*32 + i*256: all-padding tiles are skipped
             const int wave = nnf_again(tid) >> 6, lane = nnf_again(tid) & 63;
             unsigned act = 0;
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
         }
 #pragma unroll
         for (int i = 0; i < GL_NSUM; ++i) sums[i] = 0.f;
-        nnf_resolve<GL_NQ, true, false, GL_PAIR_XY>(sObj, Opad / NNF_CH, fo, 0, cx, cy, cz, qx, qy, qz, m1, m2, m3, c1, c2, best, bi);
+        nnf_resolve<GL_NQ, true, false, GL_PAIR_XY>(sObj, Opad / NNF_CH, fo, 0, cx, cy, cz, qx, qy, qz, m1, m2, m3, c1, c2, best, bi, nullptr, ef_o);
         GL_T(3);
 #pragma unroll
         for (int i = 0; i < GL_NQ; ++i) {
@@ -564,7 +566,8 @@ __global__ __launch_bounds__(GL_THREADS, 3) void grasp_loss_fwd_fast_kernel(
             cx[i] = ox[i] - fh.cx; cy[i] = oy[i] - fh.cy; cz[i] = oz[i] - fh.cz;
             best[i] = INFINITY; bj[i] = 0;
         }
-        nnf_resolve<GLF_NO, true>(sHand, Hpad / NNF_CH, fh, 0, cx, cy, cz, ox, oy, oz, m1, m2, m3, c1, c2, best, bj);
+        nnf_resolve<GLF_NO, true>(sHand, Hpad / NNF_CH, fh, 0, cx, cy, cz, ox, oy, oz, m1, m2, m3, c1, c2, best, bj, nullptr,
+                                  nnf_mfma_error_floor(fh, kh));
 #pragma unroll
         for (int i = 0; i < GLF_NO; ++i) {
             const int k = k0 + nnf_again(tid) + i * GL_THREADS;

@@ -244,6 +244,15 @@ __device__ __forceinline__ void nnf_scan(const float* __restrict__ s, int n_chun
 // (the rounding) + O(2^-25) absolute per subnormal low part <= 2^-20.8 Rp (Rp + 2 |q - c|).  NNF_MFMA_KAPPA = 2^-19 leaves 3.5x
 // on that and 13x on the largest error scripts/ab/nn_mfma16_ab.hip measures against float64 (2^-22.7); a sequential fp32
 // accumulation with truncation at every step would give 2^-18.8.
+// That bound needs the low parts to be f16 NORMALS, i.e. a lane's own |q - c| and |p - c| not much smaller than what the wave's
+// scales were chosen for.  In general a split's residual is max(2^-22 |x|, 2^-25) in SCALED units (f16 subnormal spacing 2^-24), so
+//     |error of t| <= 3 [ 2 Rp max(2^-22 |q|, 2^-25 / sq) + |q| max(2^-21 Rp, 2^-25 / sa) ]
+//                  <= 3 2^-20 Rp |q|  +  3 2^-23 Rp / sq                (1 / sa <= 2 Rp 2^-7, 1 / sq = max(Rq_wave, Rp) / [128, 256))
+// The first term is inside KAPPA Rp (Rp + 2 |q|); the second is not once the scale basis Rq_wave exceeds ~1,400 Rp -- one far
+// query in a wave (a sentinel point at 1e7 among points of size 1), or a small tile seen from far away -- and the queries NEXT to
+// that outlier then lost neighbours (found with scripts/exp/nn_prune_nonfinite.py; round 3).  nnf_mfma_error_floor = 2^-20 Rp / sq
+// (2.7 x the term) is added to E by every caller of the matrix-core pass: nothing in the usual case (5e-10 against 1.4e-7 in the
+// fused loss kernel), and with an outlier the whole wave falls back to the exact slow path -- slow, but right.
 // The A operand is rebuilt per wave from the f32 tile (no second LDS image: the block keeps its occupancy).
 typedef _Float16 nn_h8 __attribute__((ext_vector_type(8)));
 typedef float nn_f16v __attribute__((ext_vector_type(16)));
@@ -284,6 +293,10 @@ __device__ __forceinline__ NnfScales nnf_scales(float rp, float rq) {
     return k;
 }
 
+__device__ __forceinline__ float nnf_mfma_error_floor(const NnfFrame f, const NnfScales& k) {
+    return nnf_uniform(f.rp * 9.5367431640625e-7f / k.sq);      // 2^-20 Rp / sq (see the error analysis above)
+}
+
 // A operand of this lane for 32-point tile `tile` of the framed f32 tile s (n_pts points, a multiple of NNF_CH)
 __device__ __forceinline__ nn_h8 nnf_build_A(const float* __restrict__ s, int n_pts, int tile, int lane, const NnfScales& k) {
     const int col = lane & 31, h = lane >> 5;
@@ -292,7 +305,9 @@ __device__ __forceinline__ nn_h8 nnf_build_A(const float* __restrict__ s, int n_
     const int p = min(tile * 32 + prow, n_pts - 1);
     const float* d = s + (p >> 4) * NNF_CSTRIDE + ((p & 15) >> 1) * 8 + (p & 1);
     const float X = d[0], Y = d[2], Z = d[4], W = d[6];
-    const bool pad = !(fabsf(X) < 1.0e17f);
+    // pad points (NN_FAR), and any point with a non-finite or absurdly large coordinate: it can never be a nearest neighbour, and a NaN
+    // / Inf in its operand row would turn the whole chunk's minimum into NaN (v_minimum3 propagates it) and hide its 15 neighbours
+    const bool pad = !(fabsf(X) < 1.0e17f && fabsf(Y) < 1.0e17f && fabsf(Z) < 1.0e17f && fabsf(W) < 3.0e38f);
     _Float16 axh, axl, ayh, ayl, azh, azl, wh, wm, wl;
     nnf_split16(pad ? 0.f : X * k.sa, axh, axl);
     nnf_split16(pad ? 0.f : Y * k.sa, ayh, ayl);
@@ -479,12 +494,13 @@ __device__ __forceinline__ void nnf_scan_mfma_core(const float* __restrict__ s, 
 template <int NQ>
 __device__ __forceinline__ void nnf_scan_mfma(const float* __restrict__ s, int n_chunks, const NnfFrame f, const float (&qx)[NQ],
                                               const float (&qy)[NQ], const float (&qz)[NQ], float (&m1)[NQ], float (&m2)[NQ],
-                                              float (&m3)[NQ], int (&c1)[NQ], int (&c2)[NQ]) {
+                                              float (&m3)[NQ], int (&c1)[NQ], int (&c2)[NQ], float& e_floor) {
     float rq = 0.f;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) rq = fmaxf(rq, fmaxf(fabsf(qx[i]), fmaxf(fabsf(qy[i]), fabsf(qz[i]))));
     for (int o = 32; o > 0; o >>= 1) rq = fmaxf(rq, __shfl_xor(rq, o, 64));
     const NnfScales k = nnf_scales(f.rp, rq);
+    e_floor = nnf_mfma_error_floor(f, k);           // what nnf_resolve adds to its error bound for THIS wave's scales
     nnf_scan_mfma_core<NQ, false>(s, n_chunks, k, qx, qy, qz, m1, m2, m3, c1, c2);
 }
 
@@ -531,12 +547,14 @@ __device__ __forceinline__ void nnf_resolve(const float* __restrict__ s, int n_c
                                             const float (&ox)[NQ], const float (&oy)[NQ], const float (&oz)[NQ],
                                             const float (&m1)[NQ], const float (&m2)[NQ], const float (&m3)[NQ],
                                             const int (&c1)[NQ], const int (&c2)[NQ],
-                                            float (&best)[NQ], int (&bi)[NQ], const int* __restrict__ sorig = nullptr) {
+                                            float (&best)[NQ], int (&bi)[NQ], const int* __restrict__ sorig = nullptr,
+                                            float e_floor = 0.f) {
     const int lane = __lane_id();
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const float qq = __builtin_fmaf(qz[i], qz[i], __builtin_fmaf(qy[i], qy[i], qx[i] * qx[i])) * 1.001f;
-        const float E = MFMA_PASS ? NNF_MFMA_KAPPA * f.rp * (f.rp + 2.f * sqrtf(qq))
+        // (e_floor: nnf_mfma_error_floor of the scales the matrix-core pass ran with -- wave-uniform; 0 for the vector pass)
+        const float E = MFMA_PASS ? NNF_MFMA_KAPPA * f.rp * (f.rp + 2.f * sqrtf(qq)) + e_floor
                                   : 5.9604645e-7f * f.rp * (f.rp + sqrtf(qq));           // 10 u Rp (Rp + Rq)
         const float thr = m1[i] + (2.f * E + 1.0e-6f * (fmaxf(m1[i] + qq, 0.f) + E));
         // a tile whose best possible distance cannot beat the exact minimum carried in from earlier tiles is skipped:

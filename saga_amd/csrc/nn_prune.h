@@ -520,7 +520,8 @@ __global__ __launch_bounds__(NNP_THREADS, NNP_WAVES_PER_EU) void nnp_scan_kernel
             asm volatile("" : "+v"(ox[i]), "+v"(oy[i]), "+v"(oz[i]));
             cx[i] = ox[i] - f.cx; cy[i] = oy[i] - f.cy; cz[i] = oz[i] - f.cz;
         }
-        nnf_resolve<NQ, true, true>(sdb, NNP_TILE / NNF_CH, f, 0, cx, cy, cz, ox, oy, oz, m1, m2, m3, c1, c2, best, bi, sorig);
+        nnf_resolve<NQ, true, true>(sdb, NNP_TILE / NNF_CH, f, 0, cx, cy, cz, ox, oy, oz, m1, m2, m3, c1, c2, best, bi, sorig,
+                                    nnf_mfma_error_floor(f, ks));
         refresh_bounds();
         NNP_CLK(12);
     }

@@ -256,6 +256,44 @@ def test_p2p_signed_large_clouds_take_the_pruned_search(directions):
         assert not ((xidx >= 3000) & (xidx < 3100)).any()                # a duplicate at the higher index never wins its tie
 
 
+@pytest.mark.parametrize('bad', [float('nan'), float('inf'), float('-inf'), 3e38, 1e10, 1e7], ids=['nan', 'inf', '-inf', '3e38', '1e10', '1e7'])
+def test_bad_points_do_not_disturb_their_neighbours(bad):
+    """A cloud with a non-finite, absurdly large or merely far point (a sentinel at 1e7 among points of size 1): the plain scan of the
+    reference's extension just never picks it (NaN / Inf distances lose every '<').  The two-level scan and the pruned search must do
+    the same for every query that is finite itself -- round 3 found both losing neighbours: a NaN / Inf coordinate turned its whole
+    16-point chunk's minimum into NaN (the tile was then skipped for the query), and ONE far query in a wave set operand scales under
+    which its wave-mates' coordinates underflowed below the pass's error bound (nn_fast.h: pad test on every coordinate,
+    nnf_mfma_error_floor).  Both directions, both search forms, against SAGA_NN_EXACT_SCAN=1; bit-equal distances."""
+    import os
+    import saga_amd.chamfer_distance as chd
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(2, 5000, 3, generator=g) * 0.3).cuda()
+    y = (torch.randn(2, 6000, 3, generator=g) * 0.3).cuda()
+    y[0, 17, 1] = bad           # one coordinate of a point
+    y[1, 4000] = bad            # a whole point
+    x[0, 100, 0] = bad          # ... and in the other cloud (a bad QUERY of the x -> y direction, a bad database point of y -> x)
+
+    def run(env):
+        os.environ.update(env)
+        try:
+            out = chd.ChamferDistance(x, y)
+            torch.cuda.synchronize()
+        finally:
+            for k in env:
+                del os.environ[k]
+        return out
+
+    exact = run({'SAGA_NN_EXACT_SCAN': '1'})
+    ok = (torch.isfinite(x).all(-1) & (x.abs().amax(-1) < 1e6), torch.isfinite(y).all(-1) & (y.abs().amax(-1) < 1e6))
+    for name, env in (('pruned', {}), ('two-level scan', {'SAGA_NN_PRUNE': '0'})):
+        out = run(env)
+        for d in range(2):
+            assert torch.equal(out[2 + d][ok[d]], exact[2 + d][ok[d]]), '%s: neighbour indices, direction %d' % (name, d)
+            assert torch.equal(out[d][ok[d]], exact[d][ok[d]]), '%s: distances, direction %d' % (name, d)
+    # the bad points are nobody's neighbour (queries that are themselves bad aside)
+    assert not (exact[2][0][ok[0][0]] == 17).any() and not (exact[2][1][ok[0][1]] == 4000).any() and not (exact[3][0][ok[1][0]] == 100).any()
+
+
 def test_chamfer_both_call_forms_and_errors():
     import saga_amd.chamfer_distance as chd
     x = torch.randn(1, 5, 3).cuda()
