@@ -627,3 +627,72 @@ def test_motion_opt_result_schema(body_model_dir, tmp_path):
     np.testing.assert_allclose(out['body_opt']['betas'], np.broadcast_to(prob['beta'].numpy()[:, None], (S, Tn, 10)), rtol=1e-6)
     back = np.load(str(tmp_path / 'fitting_results.npy'), allow_pickle=True).item()
     assert back['object_name'] == 'camera' and back['body_opt']['body_pose'].shape == (S, Tn, 63)
+
+
+def test_motion_terms_operator_fuzz_against_fp64_restatement():
+    """saga_motion_terms_fwd/bwd on random tensors of random sizes (S 1-3, T 3-20, tails 2..T, ragged set sizes, values that cross
+    every mask threshold: foot speeds around 0.1, object -> hand distances around -3 mm, marker distances around 1 cm, contact
+    labels of every pattern incl. none / all) against a float64 restatement of MotionFill/models/fittingop.py:159-176 (contact),
+    :178-191 (collision), :193-263 (skating), :265-280 (angle), :360-368 (marker / end fit), :386-387 (hand smoothness) under
+    autograd: terms within 2e-5, gradients of the six differentiable inputs within 1e-4."""
+    g = torch.Generator().manual_seed(31)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for case in range(40):
+        S, Tn = ri(1, 3), ri(3, 20)
+        nt = ri(2, Tn)
+        M, H, O, CM, NP = ri(1, 90), ri(1, 300), ri(1, 400), ri(22, 150), 22
+        fs = [ri(1, 40) for _ in range(4)]
+        R = lambda *s, sc=1.0: torch.randn(*s, generator=g, dtype=torch.float64) * sc
+        markers, markers_rec, markers_end = R(S, Tn, M, 3), R(S, Tn, M, 3), R(S, M, 3)
+        mask = (torch.rand(M, generator=g) > 0.3).double()
+        feet = torch.cumsum(R(S, Tn, sum(fs), 3, sc=0.003), dim=1) + R(S, 1, sum(fs), 3)
+        lbl_mode = ri(0, 2)
+        lbl = torch.zeros(S, Tn, 4, dtype=torch.float64) if lbl_mode == 0 else (torch.ones(S, Tn, 4, dtype=torch.float64) if lbl_mode == 1
+                                                                               else (torch.rand(S, Tn, 4, generator=g) > 0.5).double())
+        hand_tail = torch.cumsum(R(S, nt, H, 3, sc=0.01), dim=1) + R(S, 1, H, 3)
+        o2h, h2o_mk = R(S * nt, O, sc=0.01), torch.rand(S * nt, CM, generator=g, dtype=torch.float64) * 0.03
+        h2o_vec, palm_n = R(S * nt, CM, 3, sc=0.02), torch.nn.functional.normalize(R(S * nt, NP, 3), dim=-1) * (0.5 + torch.rand(S * nt, NP, 1, generator=g, dtype=torch.float64))
+        c_obj, c_mk = torch.rand(S, O, generator=g, dtype=torch.float64), torch.rand(S, CM, generator=g, dtype=torch.float64)
+        leaves = [t.clone().requires_grad_(True) for t in (markers, feet, hand_tail, o2h, h2o_mk, h2o_vec)]
+        mk_, ft_, ht_, o2h_, hm_, hv_ = leaves
+
+        # ---- float64 restatement --------------------------------------------------------------------------------------
+        m4 = mask.view(1, 1, M, 1)
+        t_rec = (mk_ * m4 - markers_rec * m4).abs().mean(dim=(1, 2, 3))
+        t_end = (mk_[:, -1] - markers_end).abs().mean(dim=(1, 2))
+        t_sk, o = torch.zeros(S, dtype=torch.float64), 0
+        for col in range(4):
+            foot = ft_[:, :, o:o + fs[col]]
+            o += fs[col]
+            speed = ((foot[:, 1:] - foot[:, :-1]) * 30).norm(dim=-1)
+            on = (lbl[:, :-1, col] == 1)[:, :, None] & (speed > 0.1)
+            cnt = on.sum(dim=(1, 2))
+            t_sk = t_sk + torch.where(cnt > 0, (speed * on).sum(dim=(1, 2)) / cnt.clamp(min=1), torch.zeros(S, dtype=torch.float64))
+        t_hs = (ht_[:, 1:] - ht_[:, :-1]).norm(dim=-1).mean(dim=(1, 2)) if nt > 1 else torch.zeros(S, dtype=torch.float64)
+        w = torch.zeros(nt, 1, dtype=torch.float64)
+        w[-5:] = 1
+        o2h_s, hm_s = o2h_.view(S, nt, O), hm_.view(S, nt, CM)
+        t_con = (o2h_s.abs() * c_obj.view(S, 1, O) * w).mean(dim=(1, 2)) + (hm_s.abs() * c_mk.view(S, 1, CM) * w).mean(dim=(1, 2))
+        t_col = 5 * (o2h_s.abs() * torch.where(o2h_s < -0.003, 20.0, 0.0)).mean(dim=-1).mean(dim=-1)
+        vec = -hv_.view(S, nt, CM, 3)[:, :, -NP:]
+        pn = palm_n.view(S, nt, NP, 3)
+        cos = (pn * vec).sum(-1) / (pn.norm(dim=-1) * vec.norm(dim=-1))
+        wt = 1 - ((torch.arange(nt, dtype=torch.float64) + 1) / nt).view(-1, 1) ** 2
+        t_ang = ((hm_s[:, :, -NP:] < 0.01).double() * (cos - 1) ** 2 * wt).mean(dim=(1, 2))
+        ref = torch.stack([t_rec, t_end, t_sk, t_hs, t_con, t_col, t_ang], dim=1)
+        gw = R(S, 7).abs() + 0.1
+        (ref * gw).sum().backward()
+
+        # ---- the operator ---------------------------------------------------------------------------------------------
+        c = lambda t: t.detach().float().cuda()
+        hl = [c(t).requires_grad_(True) for t in leaves]
+        out = ml.motion_terms(hl[0], hl[1], fs, hl[2], hl[3], hl[4], hl[5], c(markers_rec), c(mask), c(markers_end), c(lbl), c(c_obj),
+                              c(c_mk), c(palm_n))
+        (out * c(gw)).sum().backward()
+        info = (case, S, Tn, nt, M, H, O, CM, fs, lbl_mode)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=1e-9, err_msg=str(info))
+        for name, a, b in zip(('markers', 'feet', 'hand_tail', 'o2h', 'h2o_marker', 'h2o_vec'), hl, leaves):
+            if b.grad.abs().max() == 0:
+                assert a.grad.abs().max() == 0, (name, info)
+                continue
+            assert rel_err(a.grad.cpu().numpy().reshape(-1), b.grad.numpy().reshape(-1)) < 1e-4, (name, info)
