@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 
 #include "saga_common.h"
@@ -50,6 +51,8 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
@@ -460,6 +463,255 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     }       // tiles of this block
 }
 
+
+// The forward contraction at fitting batch sizes: a PERSISTENT kernel whose tiles overlap (blend_fwd_xt_kernel).  With one tile per block
+// (gemm_nt_f32_kernel) ~9 % of a tile's time is its prologue (three k-tiles requested, nothing to multiply yet) and its epilogue (16
+// stores per wave, each waiting for a gap in the co-resident block's MFMA burst).  Here
+//   * the stores of tile i leave during the k-loop of tile i+1, the four quads of a 32 x 32 tile every eighth k-step, from a second
+//     accumulator set (2 x 64 registers; 190 VGPRs, still two blocks per CU) -- still no vector arithmetic in a k-step;
+//   * the first three k-tiles of tile i+1 are requested during the last three k-steps of tile i: the stage ring never drains;
+//   * tiles come from a queue per XCD (the two blocks of a CU progress very unequally, equal shares lose: see the launch below), drawn
+//     ONE TILE AHEAD: the ticket is requested at the start of a tile, published to the block through LDS at k-step 19 and read at
+//     k-step 21, behind barriers the k-loop has anyway;
+//   * everything the compiler would wait for with a count that ignores the LDS-DMA transfers (i.e. drain them) -- the ticket, the
+//     bias words -- is inline asm, retired by the counted waits of the k-steps between its issue and its use.
+// Same products in the same order as the one-tile kernel: same bits (tests/test_gpu_smplx.py).  0.985 -> 0.939 ms at B = 4096.
+// Full 128 x 128 tiles, K = 512, lda = ldb = 512 only.  A launch uses one of GEMM_XT_SLOTS queue slots, chosen by its stream (launches
+// of one stream run one after the other, and the last draw of a launch leaves the queue at zero for the next).
+#define GEMM_XT_SLOTS 64
+__device__ int gemm_xt_queue[GEMM_XT_SLOTS][8];
+__device__ __forceinline__ void gemm_lds_write32(uint32_t addr, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ int gemm_lds_read32_wait(uint32_t addr) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+// vector memory operations the compiler must not see: it would wait for them with counts that ignore the LDS-DMA transfers in flight
+// (i.e. drain them).  Their results are used more than three k-steps later: the counted waits of the steps between have retired them.
+__device__ __forceinline__ int gemm_atomic_inc_async(int* p) {
+    int v = 1;
+    asm volatile("global_atomic_add %0, %1, %0, off sc0" : "+v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ float gemm_load_async(const float* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__global__ __launch_bounds__(256) void blend_fwd_xt_kernel(const float* __restrict__ A, const float* __restrict__ Bt, float* __restrict__ C, int ldc,
+                                                           const float* __restrict__ bias, int tiles_m, int xcd_map, int n_tiles, int slot) {
+    constexpr int BKT = 16, NST = 4, LD = 512, T = 32, TILE_FLOATS = 128 * BKT, STAGE_BYTES = 2 * TILE_FLOATS * 4;
+    __shared__ __attribute__((aligned(1024))) float smem[NST * 2 * TILE_FLOATS + 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    auto swz = [](int row) { return (row >> 2) & 3; };
+    uint32_t off[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 16 + lane / 4;
+        off[j] = ((uint32_t)row * LD + (((lane & 3) ^ swz(row)) * 4)) * 4u;
+    }
+    const int fsw = swz(l31);
+    uint32_t fa[2], fb[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int koff = ((2 * g + half) ^ fsw) * 4;
+        fa[g] = (uint32_t)(uintptr_t)(lds_ptr_t)(smem + (wm * 64 + l31) * BKT + koff);
+        fb[g] = (uint32_t)(uintptr_t)(lds_ptr_t)(smem + TILE_FLOATS + (wn * 64 + l31) * BKT + koff);
+    }
+    const uint32_t ticket_addr = (uint32_t)(uintptr_t)(lds_ptr_t)(smem + NST * 2 * TILE_FLOATS);
+    const int qx = blockIdx.x & 7, gx = gridDim.x >> 3, nx = n_tiles >> 3;        // this XCD's queue: gx blocks, nx tiles
+    int* const queue = &gemm_xt_queue[slot][qx];
+
+    auto tile_origin = [&](int bx, int& m0, int& n0) {
+        int tile_m = bx % tiles_m, tile_n = bx / tiles_m;
+        if (xcd_map) {
+            const int x = bx & 7, i = bx >> 3;
+            const int mq = tiles_m >> 2, nh = (n_tiles / tiles_m) >> 1;
+            tile_m = (x & 3) * mq + i % mq;
+            tile_n = (x >> 2) * nh + i / mq;
+        }
+        m0 = tile_m * 128;
+        n0 = tile_n * 128;
+    };
+    auto issue = [&](auto stg, const char* ak, const char* bk) __attribute__((always_inline)) {
+        constexpr int STG = decltype(stg)::value;
+        float* sa = smem + STG * (2 * TILE_FLOATS) + wave * 512;
+        float* sb = sa + TILE_FLOATS;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            gemm_lds_dma16(off[j], ak, (uint32_t)(uintptr_t)(lds_ptr_t)(sa + j * 256));
+            gemm_lds_dma16(off[j], bk, (uint32_t)(uintptr_t)(lds_ptr_t)(sb + j * 256));
+        }
+    };
+
+    int m0, n0;
+    tile_origin(blockIdx.x, m0, n0);
+    const char* a_base = reinterpret_cast<const char*>(A + (size_t)m0 * LD);
+    const char* b_base = reinterpret_cast<const char*>(Bt + (size_t)n0 * LD);
+    const char* a_next = a_base;
+    const char* b_next = b_base;
+    float* cp_cur[2];
+    float* cp_prev[2] = {nullptr, nullptr};
+    float* cp_next[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) cp_next[mt] = cp_cur[mt] = C + (size_t)(m0 + wm * 64 + mt * 32 + l31) * ldc + n0 + wn * 64 + 4 * half;
+    float bias_cur[2], bias_next[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bias_cur[nt] = gemm_load_async(bias + n0 + wn * 64 + nt * 32 + l31);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias_cur[0]), "+v"(bias_cur[1])::"memory");
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bias_next[nt] = bias_cur[nt];
+    gemm_static_for<0, NST - 1>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int S = decltype(sc)::value;
+        issue(sc, a_base + S * BKT * 4, b_base + S * BKT * 4);
+    });
+    bool has_next = false;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // one tile: cur accumulates, prev (the tile before, if has_prev) is stored one quad per even k-step
+    auto trip = [&](f32x16 (&cur)[2][2], f32x16 (&prev)[2][2], auto hp) __attribute__((always_inline)) {
+        constexpr bool has_prev = decltype(hp)::value;
+        int ticket = 0;
+        if (tid == 0) ticket = gemm_atomic_inc_async(queue);
+        gemm_static_for<0, T>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int U = t % NST;
+            // k-tile t has landed once only what was issued after it is outstanding: two k-tiles (8 transfers) and, with a tile being
+            // stored, the four stores of k-step 0, 8, 16 or 24 if that is one of the three steps before this one; at the tail of a
+            // block's last tile nothing follows.  (Whatever else is in flight -- the ticket, the bias words -- only makes a count
+            // stricter than it need be.)
+            if (t >= T - 2 && !has_next) {
+                if (t == T - 2) gemm_wait_vmcnt<4>();
+                else gemm_wait_vmcnt<0>();
+            } else if (has_prev && t % 8 >= 1 && t % 8 <= 3) gemm_wait_vmcnt<12>();
+            else gemm_wait_vmcnt<8>();
+            __builtin_amdgcn_s_barrier();
+            if (t == 19 && tid == 0) {
+                const int i = gx + ticket;
+                if (ticket == nx - 1) atomicExch(queue, 0);      // the last draw of this queue: ready for the next launch
+                gemm_lds_write32(ticket_addr, i < nx ? qx + 8 * i : -1);
+            }
+            if (t == 21) {
+                const int nb = __builtin_amdgcn_readfirstlane(gemm_lds_read32_wait(ticket_addr));
+                has_next = nb >= 0;
+                int m1, n1;
+                tile_origin(has_next ? nb : (int)blockIdx.x, m1, n1);
+                a_next = reinterpret_cast<const char*>(A + (size_t)m1 * LD);
+                b_next = reinterpret_cast<const char*>(Bt + (size_t)n1 * LD);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) cp_next[mt] = C + (size_t)(m1 + wm * 64 + mt * 32 + l31) * ldc + n1 + wn * 64 + 4 * half;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) bias_next[nt] = gemm_load_async(bias + n1 + wn * 64 + nt * 32 + l31);
+            }
+            constexpr int SOFF = U * STAGE_BYTES;
+            gemm_f4 af[2][2], bf[2][2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                af[g][0] = gemm_lds_read128<SOFF>(fa[g]);
+                af[g][1] = gemm_lds_read128<SOFF + 32 * BKT * 4>(fa[g]);
+                bf[g][0] = gemm_lds_read128<SOFF>(fb[g]);
+                bf[g][1] = gemm_lds_read128<SOFF + 32 * BKT * 4>(fb[g]);
+            }
+            if (t + NST - 1 < T) issue(std::integral_constant<int, (U + NST - 1) % NST>(), a_base + (t + NST - 1) * BKT * 4, b_base + (t + NST - 1) * BKT * 4);
+            else if (has_next) issue(std::integral_constant<int, (U + NST - 1) % NST>(), a_next + (t + NST - 1 - T) * BKT * 4, b_next + (t + NST - 1 - T) * BKT * 4);
+            if (t % 8 == 0 && has_prev) {
+                // the four quads of one 32 x 32 tile together: with the lane pair's 32 B per row and store, they complete the
+                // rows' 128-B lines while those are still in L2 (one quad per even k-step: 0.92 GB written instead of 0.52)
+                constexpr int mt = t >> 4, nt = (t >> 3) & 1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(cp_prev[mt] + nt * 32 + 8 * q) =
+                        make_float4(prev[mt][nt][4 * q], prev[mt][nt][4 * q + 1], prev[mt][nt][4 * q + 2], prev[mt][nt][4 * q + 3]);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (g == 1) __builtin_amdgcn_sched_barrier(0);
+                if (g == 0) gemm_wait_lgkm<4>(af[0][0], af[0][1], bf[0][0], bf[0][1]);
+                else gemm_wait_lgkm<0>(af[1][0], af[1][1], bf[1][0], bf[1][1]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        if (t == 0 && g == 0) cur[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].x, af[g][mt].x, zero16, 0, 0, 0);
+                        else cur[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].x, af[g][mt].x, cur[mt][nt], 0, 0, 0);
+                        cur[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].y, af[g][mt].y, cur[mt][nt], 0, 0, 0);
+                        cur[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].z, af[g][mt].z, cur[mt][nt], 0, 0, 0);
+                        cur[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].w, af[g][mt].w, cur[mt][nt], 0, 0, 0);
+                    }
+            }
+        });
+        const float one = half ? 0.f : 1.f;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float bv = half ? 0.f : bias_cur[nt];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) cur[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, one, cur[mt][nt], 0, 0, 0);
+        }
+    };
+    auto flush = [&](f32x16 (&cur)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(cp_cur[mt] + nt * 32 + 8 * q) =
+                        make_float4(cur[mt][nt][4 * q], cur[mt][nt][4 * q + 1], cur[mt][nt][4 * q + 2], cur[mt][nt][4 * q + 3]);
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        a_base = a_next;
+        b_base = b_next;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            cp_prev[i] = cp_cur[i];
+            cp_cur[i] = cp_next[i];
+            bias_cur[i] = bias_next[i];
+        }
+    };
+    f32x16 accA[2][2], accB[2][2];
+    trip(accA, accB, std::false_type());
+    if (!has_next) {
+        flush(accA);
+        return;
+    }
+    advance();
+    for (;;) {
+        trip(accB, accA, std::true_type());
+        if (!has_next) { flush(accB); break; }
+        advance();
+        trip(accA, accB, std::true_type());
+        if (!has_next) { flush(accA); break; }
+        advance();
+    }
+}
+
+static int gemm_cu_count() {       // of the current device
+    static int n_cu[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (n_cu[dev] == 0) {
+        int v = 0;
+        n_cu[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return n_cu[dev];
+}
+// The queue slot of a stream (-1: all taken, the caller launches the one-tile kernel).  Two launches may share a slot only if they cannot
+// run at the same time: those of one stream.  (A captured launch keeps the slot of the stream it was captured on: replaying two graphs
+// captured on ONE stream at the same time on two streams is the one pattern this does not cover.)
+static int gemm_xt_slot(hipStream_t st) {
+    static std::mutex mu;
+    static hipStream_t owner[GEMM_XT_SLOTS];
+    static int n = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < n; ++i)
+        if (owner[i] == st) return i;
+    if (n == GEMM_XT_SLOTS) return -1;
+    owner[n] = st;
+    return n++;
+}
+
 // v_posed[B,Npad] = v_template + feat . Bt^T
 int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed, int B, hipStream_t st) {
     const int tiles_m = (B + BM - 1) / BM, tiles_n = m->Npad / BN;
@@ -482,6 +734,18 @@ int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed
                                                                                       nullptr, B, m->Npad, FEAT_K, FEAT_K, tm);
         SAGA_LAUNCH_CHECK();
         return 0;
+    }
+    // Fitting batch sizes (at least three tiles per block of two blocks per CU; B = 1,024 has 3.8: 0.261 -> 0.249 ms): the persistent kernel with overlapping tiles
+    // (SAGA_GEMM_XT=0: one tile per block; =n: from n tiles per block on)
+    static const int want_xt = getenv("SAGA_GEMM_XT") ? atoi(getenv("SAGA_GEMM_XT")) : 3;
+    if (want_xt && !want_lepi && B % BM == 0 && n_tiles % 8 == 0 && m->v_template) {
+        const int blocks = (2 * gemm_cu_count()) & ~7;
+        const int slot = n_tiles >= want_xt * blocks ? gemm_xt_slot(st) : -1;
+        if (slot >= 0) {
+            blend_fwd_xt_kernel<<<dim3(blocks), 256, 0, st>>>(feat, m->Bt, v_posed, m->Npad, m->v_template, tiles_m, xcd_map, n_tiles, slot);
+            SAGA_LAUNCH_CHECK();
+            return 0;
+        }
     }
     if (want_lepi) {
         grid.x = n_tiles;

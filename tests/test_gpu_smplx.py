@@ -121,6 +121,37 @@ def test_ragged_batch_on_the_large_tile_path_equals_small_batches_bit_for_bit(bo
     assert torch.isfinite(v_big).all()
 
 
+def test_overlapped_tile_forward_equals_one_tile_launches_bit_for_bit(body_model_dir):
+    """B = 2,048 runs the blend contraction's forward as the persistent kernel with overlapping tiles (16 x 246 tiles, a
+    queue per XCD, stores of one tile during the k-loop of the next); 128 candidates at a time run one 64 x 64 tile per
+    block.  Same products in the same order: every vertex of every candidate must agree bit for bit -- on two streams at
+    once as well (each stream has its own queue slot), and on a second launch (the queue is left at zero)."""
+    B = 2048
+    inp = random_body_inputs(B, seed=4321)
+    hip = make_hip_model(body_model_dir, B)
+    x = to_cuda(inp)
+    with torch.no_grad():
+        v_big = hip(return_verts=True, **x).vertices
+        small = make_hip_model(body_model_dir, 128)
+        for b0 in range(0, B, 128):
+            v = small(return_verts=True, **{k: t[b0:b0 + 128] for k, t in x.items()}).vertices
+            assert torch.equal(v_big[b0:b0 + 128], v), b0
+        assert torch.equal(hip(return_verts=True, **x).vertices, v_big)
+        torch.cuda.synchronize()
+        hip2 = make_hip_model(body_model_dir, B)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for rep in range(3):
+            with torch.cuda.stream(s1):
+                a = hip(return_verts=True, **x).vertices
+            with torch.cuda.stream(s2):
+                b = hip2(return_verts=True, **x).vertices
+            outs += [a, b]
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o, v_big)
+
+
 @pytest.mark.parametrize('variant', [
     dict(n_verts=2100, n_faces=4100, dense_weights=True),   # dense table over 3 vertex ranges: the MFMA dA reduction
     dict(n_verts=3000, n_faces=5900, weights_nnz=6),        # 6 non-zeros per vertex: generic sparse path, one block per candidate
