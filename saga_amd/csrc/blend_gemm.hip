@@ -20,7 +20,6 @@
 #include <stdlib.h>
 
 #include <algorithm>
-#include <mutex>
 #include <type_traits>
 
 #include "saga_common.h"
@@ -476,10 +475,9 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
 //   * everything the compiler would wait for with a count that ignores the LDS-DMA transfers (i.e. drain them) -- the ticket, the
 //     bias words -- is inline asm, retired by the counted waits of the k-steps between its issue and its use.
 // Same products in the same order as the one-tile kernel: same bits (tests/test_gpu_smplx.py).  0.985 -> 0.939 ms at B = 4096.
-// Full 128 x 128 tiles, K = 512, lda = ldb = 512 only.  A launch uses one of GEMM_XT_SLOTS queue slots, chosen by its stream (launches
-// of one stream run one after the other, and the last draw of a launch leaves the queue at zero for the next).
-#define GEMM_XT_SLOTS 64
-__device__ int gemm_xt_queue[GEMM_XT_SLOTS][8];
+// Full 128 x 128 tiles, K = 512, lda = ldb = 512 only.  The queue is 8 counters the CALLER provides, zero at the start of the launch:
+// saga_smplx_fwd lends the first 32 bytes of its `vertices` output, which the pose kernel before this launch zeroes and the skinning
+// kernel after it overwrites -- no state in the library, nothing shared between calls.
 __device__ __forceinline__ void gemm_lds_write32(uint32_t addr, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 __device__ __forceinline__ int gemm_lds_read32_wait(uint32_t addr) {
     int v;
@@ -499,7 +497,7 @@ __device__ __forceinline__ float gemm_load_async(const float* p) {
     return v;
 }
 __global__ __launch_bounds__(256) void blend_fwd_xt_kernel(const float* __restrict__ A, const float* __restrict__ Bt, float* __restrict__ C, int ldc,
-                                                           const float* __restrict__ bias, int tiles_m, int xcd_map, int n_tiles, int slot) {
+                                                           const float* __restrict__ bias, int tiles_m, int xcd_map, int n_tiles, int* __restrict__ queues) {
     constexpr int BKT = 16, NST = 4, LD = 512, T = 32, TILE_FLOATS = 128 * BKT, STAGE_BYTES = 2 * TILE_FLOATS * 4;
     __shared__ __attribute__((aligned(1024))) float smem[NST * 2 * TILE_FLOATS + 64];
     const int tid = threadIdx.x;
@@ -522,7 +520,7 @@ __global__ __launch_bounds__(256) void blend_fwd_xt_kernel(const float* __restri
     }
     const uint32_t ticket_addr = (uint32_t)(uintptr_t)(lds_ptr_t)(smem + NST * 2 * TILE_FLOATS);
     const int qx = blockIdx.x & 7, gx = gridDim.x >> 3, nx = n_tiles >> 3;        // this XCD's queue: gx blocks, nx tiles
-    int* const queue = &gemm_xt_queue[slot][qx];
+    int* const queue = queues + qx;
 
     auto tile_origin = [&](int bx, int& m0, int& n0) {
         int tile_m = bx % tiles_m, tile_n = bx / tiles_m;
@@ -590,7 +588,6 @@ __global__ __launch_bounds__(256) void blend_fwd_xt_kernel(const float* __restri
             __builtin_amdgcn_s_barrier();
             if (t == 19 && tid == 0) {
                 const int i = gx + ticket;
-                if (ticket == nx - 1) atomicExch(queue, 0);      // the last draw of this queue: ready for the next launch
                 gemm_lds_write32(ticket_addr, i < nx ? qx + 8 * i : -1);
             }
             if (t == 21) {
@@ -697,23 +694,19 @@ static int gemm_cu_count() {       // of the current device
     }
     return n_cu[dev];
 }
-// The queue slot of a stream (-1: all taken, the caller launches the one-tile kernel).  Two launches may share a slot only if they cannot
-// run at the same time: those of one stream.  (A captured launch keeps the slot of the stream it was captured on: replaying two graphs
-// captured on ONE stream at the same time on two streams is the one pattern this does not cover.)
-static int gemm_xt_slot(hipStream_t st) {
-    static std::mutex mu;
-    static hipStream_t owner[GEMM_XT_SLOTS];
-    static int n = 0;
-    std::lock_guard<std::mutex> lock(mu);
-    for (int i = 0; i < n; ++i)
-        if (owner[i] == st) return i;
-    if (n == GEMM_XT_SLOTS) return -1;
-    owner[n] = st;
-    return n++;
+// Whether the forward of this batch runs the persistent kernel (and needs its 8 queue counters zeroed before the launch): whole
+// 128-row tiles and at least three tiles per block of two blocks per CU (B = 1,024 on the whole mesh has 3.8: 0.261 -> 0.249 ms).
+// SAGA_GEMM_XT=0: never (one tile per block); =n: from n tiles per block on.
+bool saga_blend_fwd_uses_queue(const saga_model* m, int B) {
+    static const int want_xt = getenv("SAGA_GEMM_XT") ? atoi(getenv("SAGA_GEMM_XT")) : 3;
+    static const int want_lepi = getenv("SAGA_GEMM_LEPI") ? atoi(getenv("SAGA_GEMM_LEPI")) : 0;
+    if (want_xt <= 0 || want_lepi || B % BM != 0 || !m->v_template) return false;
+    const int n_tiles = (B / BM) * (m->Npad / BN);
+    return n_tiles % 8 == 0 && n_tiles >= want_xt * ((2 * gemm_cu_count()) & ~7);
 }
 
-// v_posed[B,Npad] = v_template + feat . Bt^T
-int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed, int B, hipStream_t st) {
+// v_posed[B,Npad] = v_template + feat . Bt^T          (queues: 8 zeroed ints for saga_blend_fwd_uses_queue(m, B) batches, else unused)
+int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed, int B, hipStream_t st, int* queues) {
     const int tiles_m = (B + BM - 1) / BM, tiles_n = m->Npad / BN;
     dim3 grid(tiles_m * tiles_n, 1, 1);
     static const int want_xcd = getenv("SAGA_GEMM_XCD") ? atoi(getenv("SAGA_GEMM_XCD")) : 1;     // SAGA_GEMM_XCD=0: plain tile order (A/B)
@@ -735,17 +728,12 @@ int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed
         SAGA_LAUNCH_CHECK();
         return 0;
     }
-    // Fitting batch sizes (at least three tiles per block of two blocks per CU; B = 1,024 has 3.8: 0.261 -> 0.249 ms): the persistent kernel with overlapping tiles
-    // (SAGA_GEMM_XT=0: one tile per block; =n: from n tiles per block on)
-    static const int want_xt = getenv("SAGA_GEMM_XT") ? atoi(getenv("SAGA_GEMM_XT")) : 3;
-    if (want_xt && !want_lepi && B % BM == 0 && n_tiles % 8 == 0 && m->v_template) {
+    // Fitting batch sizes: the persistent kernel with overlapping tiles
+    if (saga_blend_fwd_uses_queue(m, B) && queues) {
         const int blocks = (2 * gemm_cu_count()) & ~7;
-        const int slot = n_tiles >= want_xt * blocks ? gemm_xt_slot(st) : -1;
-        if (slot >= 0) {
-            blend_fwd_xt_kernel<<<dim3(blocks), 256, 0, st>>>(feat, m->Bt, v_posed, m->Npad, m->v_template, tiles_m, xcd_map, n_tiles, slot);
-            SAGA_LAUNCH_CHECK();
-            return 0;
-        }
+        blend_fwd_xt_kernel<<<dim3(blocks), 256, 0, st>>>(feat, m->Bt, v_posed, m->Npad, m->v_template, tiles_m, xcd_map, n_tiles, queues);
+        SAGA_LAUNCH_CHECK();
+        return 0;
     }
     if (want_lepi) {
         grid.x = n_tiles;

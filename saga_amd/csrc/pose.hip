@@ -98,8 +98,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void pose_fwd_kernel(
     const float* __restrict__ shape, const float* __restrict__ full_pose, const float* __restrict__ J_template,
     const float* __restrict__ J_dirs, const int32_t* __restrict__ parents, const int32_t* __restrict__ depth,
     float* __restrict__ feat, float* __restrict__ rot, float* __restrict__ jrest, float* __restrict__ chain,
-    float* __restrict__ Aout, int B, int S, int max_depth) {
+    float* __restrict__ Aout, int B, int S, int max_depth, int* __restrict__ zero8) {
     __shared__ float sG[WAVES_PER_BLOCK][NJ * 12];
+    if (zero8 && blockIdx.x == 0 && threadIdx.x < 8) zero8[threadIdx.x] = 0;      // the tile queues of the blend contraction that follows
     __shared__ float sShape[WAVES_PER_BLOCK][32];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.x * WAVES_PER_BLOCK + wave;
@@ -351,10 +352,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void pose_bwd_kernel(
 }
 
 int saga_launch_pose_fwd(const saga_model* m, const float* shape, const float* full_pose, float* feat, float* rot,
-                         float* jrest, float* chain, float* A, int B, hipStream_t st) {
+                         float* jrest, float* chain, float* A, int B, hipStream_t st, int* zero8) {
     dim3 grid((B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(64 * WAVES_PER_BLOCK);
     pose_fwd_kernel<<<grid, block, 0, st>>>(shape, full_pose, m->J_template, m->J_dirs, m->parents, m->depth, feat, rot,
-                                            jrest, chain, A, B, m->S, m->max_depth);
+                                            jrest, chain, A, B, m->S, m->max_depth, zero8);
     SAGA_LAUNCH_CHECK();
     return 0;
 }

@@ -2,11 +2,12 @@
 #include "saga_common.h"
 
 int saga_launch_pose_fwd(const saga_model* m, const float* shape, const float* full_pose, float* feat, float* rot,
-                         float* jrest, float* chain, float* A, int B, hipStream_t st);
+                         float* jrest, float* chain, float* A, int B, hipStream_t st, int* zero8);
 int saga_launch_pose_bwd(const saga_model* m, const float* dA, const float* g_pj, const float* g_jsum, const float* slabs,
                          int n_slabs, const float* rot, const float* jrest, const float* chain, const float* full_pose,
                          float* g_shape, float* g_full_pose, float* g_transl, int B, int has_verts, hipStream_t st);
-int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed, int B, hipStream_t st);
+int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed, int B, hipStream_t st, int* queues);
+bool saga_blend_fwd_uses_queue(const saga_model* m, int B);
 int saga_launch_blend_bwd(const saga_model* m, const float* g_vposed, float* slabs, int B, hipStream_t st);
 int saga_blend_bwd_splitk(const saga_model* m);
 int saga_launch_skin_fwd(const saga_model* m, const float* A, const float* v_posed, const float* transl, float* verts, int B,
@@ -109,8 +110,10 @@ int saga_smplx_fwd_sel(const saga_model_t* m, const saga_model_t* sub, const flo
                    "saga_smplx_fwd: null buffer");
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    { PROF(SAGA_PROF_POSE_FWD); if ((rc = saga_launch_pose_fwd(m, shape, full_pose, feat, rot, jrest, chain, A, B, st))) return rc; }
-    { PROF(SAGA_PROF_BLEND_FWD); if ((rc = saga_launch_blend_fwd(m, feat, v_posed, B, st))) return rc; }
+    // the persistent blend kernel draws its tiles from 8 counters: the head of `vertices`, free until the skinning kernel writes it
+    int* queues = saga_blend_fwd_uses_queue(m, B) ? reinterpret_cast<int*>(vertices) : nullptr;
+    { PROF(SAGA_PROF_POSE_FWD); if ((rc = saga_launch_pose_fwd(m, shape, full_pose, feat, rot, jrest, chain, A, B, st, queues))) return rc; }
+    { PROF(SAGA_PROF_BLEND_FWD); if ((rc = saga_launch_blend_fwd(m, feat, v_posed, B, st, queues))) return rc; }
     {
         PROF(SAGA_PROF_SKIN_FWD);
         if ((rc = sub ? saga_launch_skin_fwd_sel(m, sub, A, v_posed, transl, vertices, sel_rows, sel_verts, B, st)

@@ -124,8 +124,8 @@ def test_ragged_batch_on_the_large_tile_path_equals_small_batches_bit_for_bit(bo
 def test_overlapped_tile_forward_equals_one_tile_launches_bit_for_bit(body_model_dir):
     """B = 2,048 runs the blend contraction's forward as the persistent kernel with overlapping tiles (16 x 246 tiles, a
     queue per XCD, stores of one tile during the k-loop of the next); 128 candidates at a time run one 64 x 64 tile per
-    block.  Same products in the same order: every vertex of every candidate must agree bit for bit -- on two streams at
-    once as well (each stream has its own queue slot), and on a second launch (the queue is left at zero)."""
+    block.  Same products in the same order: every vertex of every candidate must agree bit for bit -- on a second launch
+    into the same buffers and on two streams at once as well (the queue lives in the call's own output buffer)."""
     B = 2048
     inp = random_body_inputs(B, seed=4321)
     hip = make_hip_model(body_model_dir, B)
