@@ -261,6 +261,9 @@ def rccl_gather_at_world_1(loss, params, B, device):
     from saga_amd.distributed import gather_candidates
     if os.environ.get('SAGA_BENCH_RCCL', '1') == '0':
         return gather_candidates(loss, params, n_total=B) + ('skipped (SAGA_BENCH_RCCL=0): single process, no collective',)
+    if dist.is_initialized():       # a 1-rank launch by torchrun: main() has set the group up over the launcher's store
+        gl, gp = gather_candidates(loss, params, n_total=B, force_collective=True)
+        return gl, gp, 'RCCL all_gather_into_tensor executed in the 1-rank nccl group of the launcher'
     try:
         from saga_amd.launch import free_port
         t0 = time.perf_counter()
@@ -289,7 +292,9 @@ def main():
         sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d: launch as many ranks as GPUs (or drop --gpus under torchrun)' % (args.gpus, world))
     if torch.cuda.device_count() <= local:
         sys.exit('bench.py: rank %d needs GPU %d, but %d GPU(s) are visible' % (rank, local, torch.cuda.device_count()))
-    if world > 1:
+    # Under a launcher (torchrun sets TORCHELASTIC_RUN_ID) the group comes from the launcher's store at any world size, 1 included: a
+    # tcp:// rendezvous of our own would be taken for a CLIENT of the agent's store there and wait for a server that does not exist.
+    if world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
     assert torch.cuda.is_available(), 'bench.py needs a ROCm GPU'
@@ -420,7 +425,7 @@ def main():
                 'sample': 'oracle (PyTorch CPU eager FP32, %d threads) on the same workload, %d object points; %s; %s; value = the better leg'
                           % (threads, n_obj, legs[0][1], legs[1][1])}
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     tmp.cleanup()
