@@ -560,6 +560,11 @@ int saga_motion_step(const saga_model_t* m, const saga_model_t* m_grad, const sa
 #define SAGA_PROF_NKERNELS   15
 int saga_profile_enable(int on);
 int saga_profile_read(double* total_ms_host, int32_t* count_host);
+/* Diagnostic (no counterpart in the reference): 1 if saga_smplx_fwd on a batch of B candidates of model m runs the blend
+ * contraction as the persistent kernel with overlapping tiles (whole 128-candidate tiles and enough of them; the environment
+ * switch SAGA_GEMM_XT), 0 if as one tile per block, -1 on a null model.  Same bits either way; tests use it to know which
+ * launch form they have exercised. */
+int saga_smplx_fwd_is_persistent(const saga_model_t* m, int B);
 
 #ifdef __cplusplus
 }

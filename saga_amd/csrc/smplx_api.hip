@@ -73,6 +73,8 @@ extern "C" int saga_profile_read(double* total_ms_host, int32_t* count_host) {
 
 #define PROF(id) ProfScope prof_scope_##id(id, st)
 
+extern "C" int saga_smplx_fwd_is_persistent(const saga_model_t* m, int B) { return m ? (saga_blend_fwd_uses_queue(m, B) ? 1 : 0) : -1; }
+
 // sub / sel_rows (both NULL for the plain forward): see saga_launch_skin_fwd_sel; used by saga_fit_step_sparse
 int saga_smplx_fwd_sel(const saga_model_t* m, const saga_model_t* sub, const float* shape, const float* full_pose, const float* transl,
                        float* vertices, float* joints, float* feat, float* rot, float* jrest, float* chain, float* A, float* v_posed,

@@ -121,14 +121,12 @@ def test_ragged_batch_on_the_large_tile_path_equals_small_batches_bit_for_bit(bo
     assert torch.isfinite(v_big).all()
 
 
-def test_overlapped_tile_forward_equals_one_tile_launches_bit_for_bit(body_model_dir):
-    """B = 2,048 runs the blend contraction's forward as the persistent kernel with overlapping tiles (16 x 246 tiles, a
-    queue per XCD, stores of one tile during the k-loop of the next); 128 candidates at a time run one 64 x 64 tile per
-    block.  Same products in the same order: every vertex of every candidate must agree bit for bit -- on a second launch
-    into the same buffers and on two streams at once as well (the queue lives in the call's own output buffer)."""
-    B = 2048
+def _overlapped_forward_check(body_model_dir, B, streams=True):
+    from saga_amd import _lib
     inp = random_body_inputs(B, seed=4321)
     hip = make_hip_model(body_model_dir, B)
+    h = hip.handle(torch.device('cuda', 0))
+    assert _lib.load().saga_smplx_fwd_is_persistent(h, B) == 1 and _lib.load().saga_smplx_fwd_is_persistent(h, 128) == 0
     x = to_cuda(inp)
     with torch.no_grad():
         v_big = hip(return_verts=True, **x).vertices
@@ -138,6 +136,8 @@ def test_overlapped_tile_forward_equals_one_tile_launches_bit_for_bit(body_model
             assert torch.equal(v_big[b0:b0 + 128], v), b0
         assert torch.equal(hip(return_verts=True, **x).vertices, v_big)
         torch.cuda.synchronize()
+        if not streams:
+            return
         hip2 = make_hip_model(body_model_dir, B)
         s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
         outs = []
@@ -150,6 +150,31 @@ def test_overlapped_tile_forward_equals_one_tile_launches_bit_for_bit(body_model
         torch.cuda.synchronize()
         for o in outs:
             assert torch.equal(o, v_big)
+
+
+def test_overlapped_tile_forward_equals_one_tile_launches_bit_for_bit(body_model_dir):
+    """B = 2,048 runs the blend contraction's forward as the persistent kernel with overlapping tiles (16 x 246 tiles, a
+    queue per XCD, stores of one tile during the k-loop of the next); 128 candidates at a time run one 64 x 64 tile per
+    block.  Same products in the same order: every vertex of every candidate must agree bit for bit -- on a second launch
+    into the same buffers and on two streams at once as well (the queue lives in the call's own output buffer)."""
+    _overlapped_forward_check(body_model_dir, 2048)
+
+
+@pytest.mark.parametrize('B', [512, 1024])
+def test_overlapped_tile_forward_with_one_or_two_tiles_per_block(body_model_dir, B):
+    """The persistent kernel's short walks -- blocks whose first tile is their last (no stores to interleave, nothing to
+    prefetch), blocks with two tiles (the first interleaved stores follow a tile that had none) -- only occur below the
+    batch sizes it is used for by default: SAGA_GEMM_XT=1 (read once per process, hence a child process) takes it from one
+    tile per block on.  B = 512: 984 tiles for 512 blocks, B = 1,024: 1,968."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import sys; sys.path.insert(0, %r); import tests.test_gpu_smplx as t; '
+            't._overlapped_forward_check(%r, %d, streams=False); print("CHILD_OK")' % (root, str(body_model_dir), B))
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, SAGA_GEMM_XT='1'), capture_output=True, text=True,
+                       timeout=280, cwd=root)
+    assert r.returncode == 0 and 'CHILD_OK' in r.stdout, (r.stdout[-400:], r.stderr[-1200:])
 
 
 @pytest.mark.parametrize('variant', [
