@@ -802,3 +802,54 @@ def test_fused_loss_neighbour_fuzz_against_exact_scan():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'scripts', 'exp'))
     import loss_fuzz
     assert loss_fuzz.fuzz(100, seed=2026) == 0
+
+
+def _step_fuzz_case(body_model_dir, B, O, stage, objective, seed):
+    """iteration 0 of saga_fit_step against the autograd composition from identical variables: objective, every logged term, markers"""
+    contact_loss, only_rec = objective
+    op_n, vp, idx, var_np, d = _setup(body_model_dir, B, contact_loss=contact_loss, only_rec=only_rec, n_points=O, seed=seed)
+    op_a, *_ = _setup(body_model_dir, B, contact_loss=contact_loss, only_rec=only_rec, n_points=O, seed=seed)
+    op_a.native = False
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for op in (op_n, op_a):
+        op.bm = op.bm_male
+        op.set_variables(var_np)
+    if contact_loss == 'prior' and O >= 64:
+        _immerse_object(op_n, d, B)
+        for k in ('verts_o', 'normals_o', 'oc'):
+            d[k] = np.ascontiguousarray(d[k][:, :O])
+    prob = op_n.make_problem(cu(d['markers']), cu(d['verts_o']), cu(d['normals_o']), cu(d['oc']), cu(d['mc']))
+    terms = torch.zeros(B, 16, device='cuda')
+    loss_n, mk_n = op_n.native_step(stage, prob, terms)
+    loss_a, ld, mk_a, *_ = op_a.calc_loss_contact_map(cu(d['markers']), cu(d['verts_o']), cu(d['normals_o']), cu(d['oc']),
+                                                      cu(d['mc']), 'male', None, stage, 1.0)
+    tag = 'B=%d O=%d stage=%d %s' % (B, O, stage, objective)
+    # The two paths decode the variables with different roundings (library decoder + rot6d kernels against torch), so their
+    # vertices differ by float32 rounding (~1e-6 m, up to ~2e-5 where a rotation conversion amplifies it) and every term that
+    # COUNTS vertices by the sign of a distance can differ by one vertex in a candidate or two (one point of a 100-point cloud
+    # changing side moved 'object collision' by 6 %).  The bar: every candidate within 5e-2 (collision terms 0.2), all but
+    # max(3, 10 %) of them within 1e-4 -- a wrong size path (tile padding, empty masks, B = 1) is gross on every candidate.
+    def close(got, want, name):
+        got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+        assert np.isfinite(got).all(), (name, tag)
+        err = np.abs(got - want) / np.maximum(np.abs(want), 1e-6)
+        assert err.max() < (0.2 if 'collision' in name else 5e-2), (name, tag, float(err.max()))
+        assert (err > LOSS_RTOL).sum() <= max(3, int(0.1 * B)), (name, tag, np.nonzero(err > LOSS_RTOL)[0].tolist(), float(err.max()))
+
+    close(loss_n.cpu().numpy(), loss_a.detach().cpu().numpy(), 'objective')
+    assert (mk_n - mk_a).abs().max() < 1e-4, (tag, float((mk_n - mk_a).abs().max()))
+    t = terms.cpu().numpy()
+    for i, k in enumerate(loss_ref.LOSS_KEYS):
+        close(t[:, i], ld[k].detach().cpu().numpy(), k)
+
+
+def test_fit_step_size_fuzz_against_autograd_composition(body_model_dir):
+    """Batch and object-cloud sizes nobody picked: one candidate, clouds smaller than a 32-point matrix tile, one point short of /
+    past a tile or the 2,048-point LDS tile, every stage and objective.  (scripts/exp/step_fuzz.py runs more of them.)"""
+    rng = np.random.default_rng(20250611)
+    sizes_b = [1, 2, 3, 7, 33, 65]
+    sizes_o = [1, 5, 31, 32, 33, 100, 777, 2047, 2049, 2500]
+    for case in range(12):
+        B, O = int(rng.choice(sizes_b)), int(rng.choice(sizes_o))
+        stage, objective = int(rng.integers(0, 3)), OBJECTIVES[int(rng.integers(0, 4))]
+        _step_fuzz_case(body_model_dir, B, O, stage, objective, seed=1000 + case)
