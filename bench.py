@@ -26,6 +26,8 @@ import time
 
 import hashlib
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC (before the HIP runtime starts): RCCL across processes needs it here
+
 import numpy as np
 import torch
 import torch.distributed as dist
