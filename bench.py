@@ -39,7 +39,7 @@ PEAK_F32_TFLOPS = 157.3     # MI355X dense FP32 (vector = matrix), /opt/skills/g
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (same guide; ~6.3 TB/s achievable)
 V, K_ALG = 10475, 506       # algorithmic K of the blend contraction: 20 shape + 486 pose-feature columns (padded to 512)
 PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'current_pmc_summary.json')
-GEMM_ENV_FLAGS = ('SAGA_GEMM_LEPI', 'SAGA_GEMM_XCD', 'SAGA_GEMM_XT')
+GEMM_ENV_FLAGS = ('SAGA_GEMM_LEPI', 'SAGA_GEMM_XCD', 'SAGA_GEMM_XT', 'SAGA_GEMM_XT_BWD')
 
 
 def stage_rooflines(prof, steps, B, n_obj, V=10475):
@@ -94,7 +94,7 @@ def pmc_traffic(B, n_obj, V):
     diff = [k for k in here if here[k] != there[k]]
     if diff:
         return None, 'PMC summary %s does not describe this run (differs in: %s)' % (os.path.relpath(PMC_SUMMARY, ROOT), ', '.join(diff))
-    g = [v for k, v in d.items() if k.startswith(('gemm_nt_f32_kernel', 'blend_fwd_xt_kernel')) and v.get('hbm_bytes') and v.get('mean_us', 0) > 500]
+    g = [v for k, v in d.items() if k.startswith(('gemm_nt_f32_kernel', 'blend_fwd_xt_kernel', 'blend_bwd_xt_kernel')) and v.get('hbm_bytes') and v.get('mean_us', 0) > 500]
     if not g:
         return None, 'PMC summary holds no blend GEMM launches'
     return round(sum(x['hbm_bytes'] for x in g) / len(g)), ('offline: %s (git %s), HBM-side bytes per launch, mean of the forward and backward '
@@ -395,7 +395,7 @@ def main():
                        'parallelism': 'candidates sharded, %d rank(s), no data-path collective' % world,
                        'best_of_8_mean_loss': float(best_loss.mean()), 'end_of_fit_gather': gather_note, 'kernels': kernels,
                        'stages': stage_rooflines(prof, args.steps, B, n_obj, V_eval)},
-            'roofline': {'bound': 'mfma', 'kernel': 'blend_fwd_xt_kernel + gemm_nt_f32_kernel (blend contraction: the forward and the split-K backward launch)',
+            'roofline': {'bound': 'mfma', 'kernel': 'blend_fwd_xt_kernel + blend_bwd_xt_kernel (blend contraction: the forward and the split-K backward launch; gemm_nt_f32_kernel at small batches)',
                          'achieved': None if achieved is None else round(achieved, 2), 'peak': PEAK_F32_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': None if achieved is None else round(achieved / PEAK_F32_TFLOPS, 4),
                          'traffic': None, 'traffic_source': None,

@@ -193,6 +193,7 @@ PROTOTYPES = {
     'saga_profile_enable': (ctypes.c_int, [ctypes.c_int]),
     'saga_profile_read': (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),
     'saga_smplx_fwd_is_persistent': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'saga_smplx_bwd_is_persistent': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
 }
 
 PROF_KERNELS = ['pose_fwd', 'blend_gemm_fwd', 'skin_fwd', 'joints', 'skin_bwd', 'blend_gemm_bwd', 'pose_bwd',

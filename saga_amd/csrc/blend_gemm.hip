@@ -684,6 +684,182 @@ __global__ __launch_bounds__(256) void blend_fwd_xt_kernel(const float* __restri
     }
 }
 
+// The split-K backward contraction the same way (slabs[z] = g_v_posed[:, kz] . Bk[:, kz]^T; EPI 1 of gemm_nt_f32_kernel): its tiles are
+// 124 (last slab: 108) k-steps long, so the k-loop is a 28-step prefix (fully unrolled: the stores of the tile before, the ticket),
+// a counted loop of four-step groups, and a last group that requests the next tile's first k-tiles.  XCD x owns the slabs z = x (mod 8)
+// as in the one-tile launch (xcd_map 2), and its queue hands out their tiles with the four N tiles of an M tile together.  Whole
+// 128-row tiles, N = 512, every slab a multiple of 64 columns and at least 512 long; 4 LDS stages (the one-tile launch: 5).
+__global__ __launch_bounds__(256) void blend_bwd_xt_kernel(const float* __restrict__ A, const float* __restrict__ Bt, float* __restrict__ C, int ld,
+                                                           int M, int K, int kchunk, int tiles_m, int n_slab, int* __restrict__ queues) {
+    constexpr int BKT = 16, NST = 4, TILE_FLOATS = 128 * BKT, STAGE_BYTES = 2 * TILE_FLOATS * 4, LDC = FEAT_K, TILES_N = FEAT_K / 128, PRE = 28;
+    __shared__ __attribute__((aligned(1024))) float smem[NST * 2 * TILE_FLOATS + 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    auto swz = [](int row) { return (row >> 2) & 3; };
+    uint32_t off[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 16 + lane / 4;
+        off[j] = ((uint32_t)row * (uint32_t)ld + (((lane & 3) ^ swz(row)) * 4)) * 4u;
+    }
+    const int fsw = swz(l31);
+    uint32_t fa[2], fb[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int koff = ((2 * g + half) ^ fsw) * 4;
+        fa[g] = (uint32_t)(uintptr_t)(lds_ptr_t)(smem + (wm * 64 + l31) * BKT + koff);
+        fb[g] = (uint32_t)(uintptr_t)(lds_ptr_t)(smem + TILE_FLOATS + (wn * 64 + l31) * BKT + koff);
+    }
+    const uint32_t ticket_addr = (uint32_t)(uintptr_t)(lds_ptr_t)(smem + NST * 2 * TILE_FLOATS);
+    const int per_slab = tiles_m * TILES_N;
+    const int qx = blockIdx.x & 7, gx = gridDim.x >> 3, nx = per_slab * (n_slab >> 3);      // this XCD's queue: gx blocks, nx tiles
+    int* const queue = queues + qx;
+    uint32_t lane_c[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) lane_c[mt] = (uint32_t)((wm * 64 + mt * 32 + l31) * LDC + wn * 64 + 4 * half);
+
+    // tile i of this XCD's queue -> operand bases (bytes), output tile origin (floats), k-steps
+    auto tile_of = [&](int i, const char*& ab, const char*& bb, size_t& c0, int& T) {
+        const int slab = qx + 8 * (i / per_slab), t = i % per_slab;
+        const int m0 = (t / TILES_N) * 128, n0 = (t % TILES_N) * 128;
+        const int k_begin = slab * kchunk;
+        T = (min(K, k_begin + kchunk) - k_begin) / BKT;
+        ab = reinterpret_cast<const char*>(A + (size_t)m0 * ld + k_begin);
+        bb = reinterpret_cast<const char*>(Bt + (size_t)n0 * ld + k_begin);
+        c0 = ((size_t)slab * M + m0) * LDC + n0;
+    };
+    auto issue = [&](auto stg, const char* ak, const char* bk) __attribute__((always_inline)) {
+        constexpr int STG = decltype(stg)::value;
+        float* sa = smem + STG * (2 * TILE_FLOATS) + wave * 512;
+        float* sb = sa + TILE_FLOATS;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            gemm_lds_dma16(off[j], ak, (uint32_t)(uintptr_t)(lds_ptr_t)(sa + j * 256));
+            gemm_lds_dma16(off[j], bk, (uint32_t)(uintptr_t)(lds_ptr_t)(sb + j * 256));
+        }
+    };
+
+    const char *a_base, *b_base, *a_next, *b_next;
+    size_t c_cur, c_next;
+    int T, T_next;
+    tile_of(blockIdx.x >> 3, a_base, b_base, c_cur, T);
+    a_next = a_base; b_next = b_base; c_next = c_cur; T_next = T;
+    float* cp_cur[2];
+    float* cp_prev[2] = {nullptr, nullptr};
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) cp_cur[mt] = C + c_cur + lane_c[mt];
+    gemm_static_for<0, NST - 1>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int S = decltype(sc)::value;
+        issue(sc, a_base + S * BKT * 4, b_base + S * BKT * 4);
+    });
+    bool has_next = false;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    auto trip = [&](f32x16 (&cur)[2][2], f32x16 (&prev)[2][2], auto hp) __attribute__((always_inline)) {
+        constexpr bool has_prev = decltype(hp)::value;
+        int ticket = 0;
+        if (tid == 0) ticket = gemm_atomic_inc_async(queue);
+        // one k-step.  PH 0: step TC of the prefix (a constant); PH 1: a step of the counted loop, t = tr; PH 2: step T - 4 + TC
+        auto kstep = [&](auto phc, auto tcc, const int tr) __attribute__((always_inline)) {
+            constexpr int PH = decltype(phc)::value, TC = decltype(tcc)::value, U = TC % NST;
+            // what is outstanding behind k-tile t: two k-tiles (8 transfers) and, behind the prefix steps 0, 8, 16, 24 of a tile whose
+            // predecessor is being stored, that step's four stores; at the tail of a block's last tile nothing follows
+            if (PH == 2 && U >= 2 && !has_next) {
+                if (U == 2) gemm_wait_vmcnt<4>();
+                else gemm_wait_vmcnt<0>();
+            } else if (PH == 0 && has_prev && TC % 8 >= 1 && TC % 8 <= 3) gemm_wait_vmcnt<12>();
+            else gemm_wait_vmcnt<8>();
+            __builtin_amdgcn_s_barrier();
+            if (PH == 0 && TC == 19 && tid == 0) {
+                const int i = gx + ticket;
+                gemm_lds_write32(ticket_addr, i < nx ? i : -1);
+            }
+            if (PH == 0 && TC == 21) {
+                const int ni = __builtin_amdgcn_readfirstlane(gemm_lds_read32_wait(ticket_addr));
+                has_next = ni >= 0;
+                tile_of(has_next ? ni : 0, a_next, b_next, c_next, T_next);
+            }
+            constexpr int SOFF = U * STAGE_BYTES;
+            gemm_f4 af[2][2], bf[2][2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                af[g][0] = gemm_lds_read128<SOFF>(fa[g]);
+                af[g][1] = gemm_lds_read128<SOFF + 32 * BKT * 4>(fa[g]);
+                bf[g][0] = gemm_lds_read128<SOFF>(fb[g]);
+                bf[g][1] = gemm_lds_read128<SOFF + 32 * BKT * 4>(fb[g]);
+            }
+            constexpr auto stg = std::integral_constant<int, (U + NST - 1) % NST>();
+            if (PH == 0) issue(stg, a_base + (TC + NST - 1) * BKT * 4, b_base + (TC + NST - 1) * BKT * 4);
+            else if (PH == 1) issue(stg, a_base + (tr + NST - 1) * BKT * 4, b_base + (tr + NST - 1) * BKT * 4);
+            else if (U == 0) issue(stg, a_base + (T - 1) * BKT * 4, b_base + (T - 1) * BKT * 4);
+            else if (has_next) issue(stg, a_next + (U - 1) * BKT * 4, b_next + (U - 1) * BKT * 4);
+            if (PH == 0 && TC % 8 == 0 && has_prev) {
+                constexpr int mt = (TC >> 4) & 1, nt = (TC >> 3) & 1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(cp_prev[mt] + nt * 32 + 8 * q) =
+                        make_float4(prev[mt][nt][4 * q], prev[mt][nt][4 * q + 1], prev[mt][nt][4 * q + 2], prev[mt][nt][4 * q + 3]);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (g == 1) __builtin_amdgcn_sched_barrier(0);
+                if (g == 0) gemm_wait_lgkm<4>(af[0][0], af[0][1], bf[0][0], bf[0][1]);
+                else gemm_wait_lgkm<0>(af[1][0], af[1][1], bf[1][0], bf[1][1]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        if (PH == 0 && TC == 0 && g == 0) cur[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].x, af[g][mt].x, zero16, 0, 0, 0);
+                        else cur[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].x, af[g][mt].x, cur[mt][nt], 0, 0, 0);
+                        cur[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].y, af[g][mt].y, cur[mt][nt], 0, 0, 0);
+                        cur[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].z, af[g][mt].z, cur[mt][nt], 0, 0, 0);
+                        cur[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g][nt].w, af[g][mt].w, cur[mt][nt], 0, 0, 0);
+                    }
+            }
+        };
+        gemm_static_for<0, PRE>([&](auto tc) __attribute__((always_inline)) { kstep(std::integral_constant<int, 0>(), tc, 0); });
+        for (int tt = PRE; tt < T - NST; tt += NST)
+            gemm_static_for<0, NST>([&](auto uc) __attribute__((always_inline)) { kstep(std::integral_constant<int, 1>(), uc, tt + decltype(uc)::value); });
+        gemm_static_for<0, NST>([&](auto uc) __attribute__((always_inline)) { kstep(std::integral_constant<int, 2>(), uc, 0); });
+    };
+    auto flush = [&](f32x16 (&cur)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(cp_cur[mt] + nt * 32 + 8 * q) =
+                        make_float4(cur[mt][nt][4 * q], cur[mt][nt][4 * q + 1], cur[mt][nt][4 * q + 2], cur[mt][nt][4 * q + 3]);
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        a_base = a_next;
+        b_base = b_next;
+        T = T_next;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            cp_prev[i] = cp_cur[i];
+            cp_cur[i] = C + c_next + lane_c[i];
+        }
+    };
+    f32x16 accA[2][2], accB[2][2];
+    trip(accA, accB, std::false_type());
+    if (!has_next) {
+        flush(accA);
+        return;
+    }
+    advance();
+    for (;;) {
+        trip(accB, accA, std::true_type());
+        if (!has_next) { flush(accB); break; }
+        advance();
+        trip(accA, accB, std::true_type());
+        if (!has_next) { flush(accA); break; }
+        advance();
+    }
+}
+
 static int gemm_cu_count() {       // of the current device
     static int n_cu[64] = {0};
     int dev = 0;
@@ -772,11 +948,35 @@ int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed
 // not depend on the batch size.
 int saga_blend_bwd_splitk(const saga_model* m) { return std::min(SAGA_BWD_SPLITK, std::max(1, m->Npad / 768)); }
 
-// slabs[z][B][512] = g_v_posed[:, kz] . Bk[:, kz]^T
-int saga_launch_blend_bwd(const saga_model* m, const float* g_vposed, float* slabs, int B, hipStream_t st) {
+// Whether the backward of this batch runs the persistent kernel (and needs its 8 queue counters zeroed before the launch): whole
+// 128-row tiles, slabs dealt to the XCDs whole (a multiple of 8 of them), every slab a whole number of four-step groups and at
+// least 32 k-steps long, and at least three tiles per block of two blocks per CU (B = 4,096 on the whole mesh has four).
+// SAGA_GEMM_XT=0 or SAGA_GEMM_XT_BWD=0: never.
+bool saga_blend_bwd_uses_queue(const saga_model* m, int B) {
+    static const int want_xt = getenv("SAGA_GEMM_XT") ? atoi(getenv("SAGA_GEMM_XT")) : 3;
+    static const int want_bwd = getenv("SAGA_GEMM_XT_BWD") ? atoi(getenv("SAGA_GEMM_XT_BWD")) : 1;
+    static const int want_xcd = getenv("SAGA_GEMM_XCD") ? atoi(getenv("SAGA_GEMM_XCD")) : 1;
+    if (want_xt <= 0 || !want_bwd || !want_xcd || B <= 0 || B % BM != 0) return false;
+    const int splitk = saga_blend_bwd_splitk(m);
+    if (splitk % 8 != 0) return false;
+    const int kchunk = saga_roundup((m->Npad + splitk - 1) / splitk, 32);
+    const int last = m->Npad - (splitk - 1) * kchunk;
+    if (kchunk % (4 * GEMM_BKT) != 0 || last % (4 * GEMM_BKT) != 0 || last < 32 * GEMM_BKT) return false;
+    const int n_tiles = (B / BM) * (FEAT_K / BN) * splitk;
+    return n_tiles >= want_xt * ((2 * gemm_cu_count()) & ~7);
+}
+
+// slabs[z][B][512] = g_v_posed[:, kz] . Bk[:, kz]^T          (queues: 8 zeroed ints for saga_blend_bwd_uses_queue(m, B) batches, else unused)
+int saga_launch_blend_bwd(const saga_model* m, const float* g_vposed, float* slabs, int B, hipStream_t st, int* queues) {
     const int tiles_m = (B + BM - 1) / BM, tiles_n = FEAT_K / BN;
     const int splitk = saga_blend_bwd_splitk(m);
     const int kchunk = saga_roundup((m->Npad + splitk - 1) / splitk, 32);
+    if (queues && saga_blend_bwd_uses_queue(m, B)) {
+        const int blocks = (2 * gemm_cu_count()) & ~7;
+        blend_bwd_xt_kernel<<<dim3(blocks), 256, 0, st>>>(g_vposed, m->Bk, slabs, m->Npad, B, m->Npad, kchunk, tiles_m, splitk, queues);
+        SAGA_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 grid(tiles_m * tiles_n, 1, splitk);
     static const int want_xcd = getenv("SAGA_GEMM_XCD") ? atoi(getenv("SAGA_GEMM_XCD")) : 1;     // SAGA_GEMM_XCD=0: plain tile order (A/B)
     const int xcd_map = (want_xcd && splitk % 8 == 0) ? 2 : 0;

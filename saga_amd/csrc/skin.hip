@@ -491,7 +491,9 @@ __global__ __launch_bounds__(DS_THREADS, 4) void skin_bwd_sparse_kernel(
     const float* __restrict__ g_verts, const float* __restrict__ v_posed, const float* __restrict__ A,
     const int32_t* __restrict__ w_idx, const float* __restrict__ w_val, const int2* __restrict__ ds_ent,
     const int32_t* __restrict__ ds_meta, const int32_t* __restrict__ ds_item_ptr, float* __restrict__ g_vposed,
-    float* __restrict__ dA_part, int V, int Npad, int KW, int Vr, int n_ranges, int rpb, int dA_stride, size_t part_stride) {
+    float* __restrict__ dA_part, int V, int Npad, int KW, int Vr, int n_ranges, int rpb, int dA_stride, size_t part_stride,
+    int* __restrict__ zero8) {
+    if (zero8 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) zero8[threadIdx.x] = 0;      // the tile queues of the blend contraction that follows
     __shared__ __attribute__((aligned(16))) float sX[DS_VR * 6];     // phase 1/2: [vertex][g.xyz, p.xyz]; phase 3: [12][DS_THREADS]
     __shared__ __attribute__((aligned(16))) float sA[NJ * 12];
     __shared__ float sG[DS_THREADS / 64][4];
@@ -742,8 +744,10 @@ __global__ void da_sum_kernel(const float* __restrict__ part, float* __restrict_
 }
 
 // scratch: >= 3 * B * dA_stride floats, free for the duration of the call (the split-K slabs, written later), or NULL
+// zero8 (optional): 8 ints this launch sets to zero for the kernel after it; *zeroed says whether it did (only the streaming kernel does)
 int saga_launch_skin_bwd(const saga_model* m, const float* A, const float* g_verts, const float* v_posed, float* g_vposed,
-                         float* dA, int dA_stride, float* scratch, int B, hipStream_t st) {
+                         float* dA, int dA_stride, float* scratch, int B, hipStream_t st, int* zero8, bool* zeroed) {
+    if (zeroed) *zeroed = false;
     static const int force_mfma = getenv("SAGA_DA_MFMA") != nullptr;      // cross-check switch: the dense MFMA reduction
     if (m->ds_parts > 0 && scratch && !force_mfma) {
         // one block per candidate walks every range (B = 4096: exactly 4 rounds of 4 blocks per CU; two blocks per candidate with
@@ -757,12 +761,13 @@ int saga_launch_skin_bwd(const saga_model* m, const float* A, const float* g_ver
         if (m->KW == 4)
             skin_bwd_sparse_kernel<true><<<grid, DS_THREADS, 0, st>>>(g_verts, v_posed, A, m->w_idx, m->w_val, m->ds_ent, m->ds_meta,
                                                                       m->ds_item_ptr, g_vposed, out, m->V, m->Npad, m->KW, m->ds_vr,
-                                                                      m->ds_parts, rpb, dA_stride, part_stride);
+                                                                      m->ds_parts, rpb, dA_stride, part_stride, zero8);
         else
             skin_bwd_sparse_kernel<false><<<grid, DS_THREADS, 0, st>>>(g_verts, v_posed, A, m->w_idx, m->w_val, m->ds_ent, m->ds_meta,
                                                                        m->ds_item_ptr, g_vposed, out, m->V, m->Npad, m->KW, m->ds_vr,
-                                                                       m->ds_parts, rpb, dA_stride, part_stride);
+                                                                       m->ds_parts, rpb, dA_stride, part_stride, zero8);
         SAGA_LAUNCH_CHECK();
+        if (zeroed) *zeroed = zero8 != nullptr;
         if (halves > 1) {
             const int n = B * (DA_ROWS * 12);
             da_sum_kernel<<<(n + 255) / 256, 256, 0, st>>>(scratch, dA, B, dA_stride, halves, part_stride);

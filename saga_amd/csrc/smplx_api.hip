@@ -1,4 +1,6 @@
 // extern "C" orchestration of the SMPL-X forward / backward (kernel sequence on one stream, no allocation, no sync).
+#include <stdlib.h>
+
 #include "saga_common.h"
 
 int saga_launch_pose_fwd(const saga_model* m, const float* shape, const float* full_pose, float* feat, float* rot,
@@ -8,7 +10,8 @@ int saga_launch_pose_bwd(const saga_model* m, const float* dA, const float* g_pj
                          float* g_shape, float* g_full_pose, float* g_transl, int B, int has_verts, hipStream_t st);
 int saga_launch_blend_fwd(const saga_model* m, const float* feat, float* v_posed, int B, hipStream_t st, int* queues);
 bool saga_blend_fwd_uses_queue(const saga_model* m, int B);
-int saga_launch_blend_bwd(const saga_model* m, const float* g_vposed, float* slabs, int B, hipStream_t st);
+int saga_launch_blend_bwd(const saga_model* m, const float* g_vposed, float* slabs, int B, hipStream_t st, int* queues);
+bool saga_blend_bwd_uses_queue(const saga_model* m, int B);
 int saga_blend_bwd_splitk(const saga_model* m);
 int saga_launch_skin_fwd(const saga_model* m, const float* A, const float* v_posed, const float* transl, float* verts, int B,
                          hipStream_t st);
@@ -19,7 +22,7 @@ int saga_launch_joints_fwd(const saga_model* m, const float* chain, const float*
 int saga_launch_joints_bwd(const saga_model* m, const float* g_joints, float* g_pj, float* g_jsum, float* gv, int B,
                            int small_stride, hipStream_t st);
 int saga_launch_skin_bwd(const saga_model* m, const float* A, const float* g_verts, const float* v_posed, float* g_vposed,
-                         float* dA, int dA_stride, float* scratch, int B, hipStream_t st);
+                         float* dA, int dA_stride, float* scratch, int B, hipStream_t st, int* zero8, bool* zeroed);
 
 // ---- optional per-kernel timing (HIP events on the launch stream) -------------------------------------------
 // bench.py turns this on for its timed region: every kernel launch of the path is bracketed by an event pair on
@@ -74,6 +77,10 @@ extern "C" int saga_profile_read(double* total_ms_host, int32_t* count_host) {
 #define PROF(id) ProfScope prof_scope_##id(id, st)
 
 extern "C" int saga_smplx_fwd_is_persistent(const saga_model_t* m, int B) { return m ? (saga_blend_fwd_uses_queue(m, B) ? 1 : 0) : -1; }
+extern "C" int saga_smplx_bwd_is_persistent(const saga_model_t* m, int B) {
+    static const int force_mfma = getenv("SAGA_DA_MFMA") != nullptr;       // (the dense skinning backward does not zero the queue)
+    return m ? ((saga_blend_bwd_uses_queue(m, B) && m->ds_parts > 0 && !force_mfma) ? 1 : 0) : -1;
+}
 
 // sub / sel_rows (both NULL for the plain forward): see saga_launch_skin_fwd_sel; used by saga_fit_step_sparse
 int saga_smplx_fwd_sel(const saga_model_t* m, const saga_model_t* sub, const float* shape, const float* full_pose, const float* transl,
@@ -163,8 +170,11 @@ extern "C" int saga_smplx_bwd(const saga_model_t* m, const float* g_vertices, co
     }
     if (has_verts) {
         SAGA_CHECK_ARG(ws_gvp && ws_slab, "saga_smplx_bwd: workspace missing");
-        { PROF(SAGA_PROF_SKIN_BWD); if ((rc = saga_launch_skin_bwd(m, A, gv, v_posed, ws_gvp, ws_dA, stride, ws_slab, B, st))) return rc; }
-        { PROF(SAGA_PROF_BLEND_BWD); if ((rc = saga_launch_blend_bwd(m, ws_gvp, ws_slab, B, st))) return rc; }
+        // the persistent blend kernel draws its tiles from 8 counters: the head of g_full_pose, free until the pose kernel writes it
+        int* queues = saga_blend_bwd_uses_queue(m, B) ? reinterpret_cast<int*>(g_full_pose) : nullptr;
+        bool zeroed = false;
+        { PROF(SAGA_PROF_SKIN_BWD); if ((rc = saga_launch_skin_bwd(m, A, gv, v_posed, ws_gvp, ws_dA, stride, ws_slab, B, st, queues, &zeroed))) return rc; }
+        { PROF(SAGA_PROF_BLEND_BWD); if ((rc = saga_launch_blend_bwd(m, ws_gvp, ws_slab, B, st, zeroed ? queues : nullptr))) return rc; }
     }
     PROF(SAGA_PROF_POSE_BWD);
     return saga_launch_pose_bwd(m, ws_dA, g_pj, g_jsum, ws_slab, saga_blend_bwd_splitk(m), rot, jrest, chain, full_pose, g_shape, g_full_pose,

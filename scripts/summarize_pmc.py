@@ -15,7 +15,7 @@ import sys
 
 root = sys.argv[1]
 csv.field_size_limit(1 << 30)
-OURS = ('gemm_nt', 'blend_fwd_xt', 'skin_', 'pose_', 'joints_', 'grasp_loss', 'nn_scan', 'nn_fast', 'vertex_normals', 'cont6d', 'rodrigues',
+OURS = ('gemm_nt', 'blend_fwd_xt', 'blend_bwd_xt', 'skin_', 'pose_', 'joints_', 'grasp_loss', 'nn_scan', 'nn_fast', 'vertex_normals', 'cont6d', 'rodrigues',
         'params_', 'loss_sum', 'adam_', 'best_update', 'hand_ring', 'p2p_', 'pick_rows', 'nn_grad', 'da_sum')
 
 
@@ -78,7 +78,7 @@ for k in sorted(cnt):
 csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'saga_amd', 'csrc')
 meta = {'src_sha16': {os.path.basename(p): hashlib.sha256(open(p, 'rb').read()).hexdigest()[:16]
                       for p in sorted(glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.h')))},
-        'env': {k: os.environ.get(k, '') for k in ('SAGA_GEMM_LEPI', 'SAGA_GEMM_XCD', 'SAGA_GEMM_XT')},
+        'env': {k: os.environ.get(k, '') for k in ('SAGA_GEMM_LEPI', 'SAGA_GEMM_XCD', 'SAGA_GEMM_XT', 'SAGA_GEMM_XT_BWD')},
         'kernels': sorted(k for k in out if k.startswith(OURS))}
 try:
     line = [l for l in open(os.path.join(root, 'bench_trace.json')) if l.startswith('{')][-1]

@@ -160,18 +160,54 @@ def test_overlapped_tile_forward_equals_one_tile_launches_bit_for_bit(body_model
     _overlapped_forward_check(body_model_dir, 2048)
 
 
-@pytest.mark.parametrize('B', [512, 1024])
+def _overlapped_backward_check(body_model_dir, B, chunks=None):
+    from saga_amd import _lib
+    inp = random_body_inputs(B, seed=99)
+    w = torch.randn(B, 10475, 3, generator=torch.Generator().manual_seed(3))
+    hip = make_hip_model(body_model_dir, B)
+    h = hip.handle(torch.device('cuda', 0))
+    assert _lib.load().saga_smplx_bwd_is_persistent(h, B) == 1 and _lib.load().saga_smplx_bwd_is_persistent(h, 128) == 0
+
+    def run(model, b0, n):
+        x = to_cuda({k: v[b0:b0 + n] for k, v in inp.items()}, requires_grad=True)
+        out = model(return_verts=True, **x)
+        (out.vertices * w[b0:b0 + n].cuda()).sum().backward()
+        return {k: v.grad for k, v in x.items()}
+
+    g_big = run(hip, 0, B)
+    g_again = run(hip, 0, B)
+    for k in g_big:
+        assert torch.equal(g_big[k], g_again[k]), k
+        assert g_big[k].abs().max() > 0 and torch.isfinite(g_big[k]).all(), k
+    small = make_hip_model(body_model_dir, 128)
+    for b0 in (range(0, B, 128) if chunks is None else chunks):
+        g = run(small, b0, 128)
+        for k in g:
+            assert torch.equal(g_big[k][b0:b0 + 128], g[k]), (k, b0)
+
+
+def test_overlapped_tile_backward_equals_one_tile_launches_bit_for_bit(body_model_dir):
+    """B = 3,072 runs the split-K backward of the blend contraction as the persistent kernel with overlapping tiles (24 x 4
+    tiles x 16 slabs, the last slab shorter; the forward too); 128 candidates at a time run 64 x 64 tiles, one per block.
+    Same products in the same order within every slab: every parameter gradient of every candidate must agree bit for bit,
+    and a second backward into the same buffers as well."""
+    _overlapped_backward_check(body_model_dir, 3072)
+
+
+@pytest.mark.parametrize('B', [512, 1024, 2048])
 def test_overlapped_tile_forward_with_one_or_two_tiles_per_block(body_model_dir, B):
     """The persistent kernel's short walks -- blocks whose first tile is their last (no stores to interleave, nothing to
     prefetch), blocks with two tiles (the first interleaved stores follow a tile that had none) -- only occur below the
     batch sizes it is used for by default: SAGA_GEMM_XT=1 (read once per process, hence a child process) takes it from one
-    tile per block on.  B = 512: 984 tiles for 512 blocks, B = 1,024: 1,968."""
+    tile per block on.  B = 512: 984 tiles for 512 blocks, B = 1,024: 1,968 -- and the backward with exactly one tile per block
+    (B = 1,024: 512 tiles) and two (B = 2,048)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ('import sys; sys.path.insert(0, %r); import tests.test_gpu_smplx as t; '
-            't._overlapped_forward_check(%r, %d, streams=False); print("CHILD_OK")' % (root, str(body_model_dir), B))
+            't._overlapped_forward_check(%r, %d, streams=False); %s print("CHILD_OK")'
+            % (root, str(body_model_dir), B, 't._overlapped_backward_check(%r, %d);' % (str(body_model_dir), B) if B >= 1024 else ''))
     r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, SAGA_GEMM_XT='1'), capture_output=True, text=True,
                        timeout=280, cwd=root)
     assert r.returncode == 0 and 'CHILD_OK' in r.stdout, (r.stdout[-400:], r.stderr[-1200:])
