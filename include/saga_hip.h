@@ -565,7 +565,7 @@ int saga_profile_read(double* total_ms_host, int32_t* count_host);
  * switch SAGA_GEMM_XT), 0 if as one tile per block, -1 on a null model.  Same bits either way; tests use it to know which
  * launch form they have exercised. */
 int saga_smplx_fwd_is_persistent(const saga_model_t* m, int B);
-/* The same for the split-K backward contraction of saga_smplx_bwd (needs more tiles: B >= 3,072 on the whole mesh with 256 CUs; only
+/* The same for the split-K backward contraction of saga_smplx_bwd (B >= 1,024 on the whole mesh with 256 CUs; only
  * behind the streaming skinning backward of sparse weight tables; switches SAGA_GEMM_XT, SAGA_GEMM_XT_BWD). */
 int saga_smplx_bwd_is_persistent(const saga_model_t* m, int B);
 

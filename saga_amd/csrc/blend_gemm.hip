@@ -871,10 +871,11 @@ static int gemm_cu_count() {       // of the current device
     return n_cu[dev];
 }
 // Whether the forward of this batch runs the persistent kernel (and needs its 8 queue counters zeroed before the launch): whole
-// 128-row tiles and at least three tiles per block of two blocks per CU (B = 1,024 on the whole mesh has 3.8: 0.261 -> 0.249 ms).
+// 128-row tiles and at least one tile per block of two blocks per CU (B >= 512 on the whole mesh; measured from one tile per block
+// on: B = 512 0.137 -> 0.134 ms, B = 1,024 0.261 -> 0.249 ms).
 // SAGA_GEMM_XT=0: never (one tile per block); =n: from n tiles per block on.
 bool saga_blend_fwd_uses_queue(const saga_model* m, int B) {
-    static const int want_xt = getenv("SAGA_GEMM_XT") ? atoi(getenv("SAGA_GEMM_XT")) : 3;
+    static const int want_xt = getenv("SAGA_GEMM_XT") ? atoi(getenv("SAGA_GEMM_XT")) : 1;
     static const int want_lepi = getenv("SAGA_GEMM_LEPI") ? atoi(getenv("SAGA_GEMM_LEPI")) : 0;
     if (want_xt <= 0 || want_lepi || B % BM != 0 || !m->v_template) return false;
     const int n_tiles = (B / BM) * (m->Npad / BN);
@@ -950,10 +951,11 @@ int saga_blend_bwd_splitk(const saga_model* m) { return std::min(SAGA_BWD_SPLITK
 
 // Whether the backward of this batch runs the persistent kernel (and needs its 8 queue counters zeroed before the launch): whole
 // 128-row tiles, slabs dealt to the XCDs whole (a multiple of 8 of them), every slab a whole number of four-step groups and at
-// least 32 k-steps long, and at least three tiles per block of two blocks per CU (B = 4,096 on the whole mesh has four).
+// least 32 k-steps long, and at least one tile per block of two blocks per CU (B >= 1,024 on the whole mesh; B = 1,024, one tile per
+// block: 0.237 -> 0.228 ms; B = 2,048: 0.460 -> 0.449; B = 4,096: 0.91 -> 0.885).
 // SAGA_GEMM_XT=0 or SAGA_GEMM_XT_BWD=0: never.
 bool saga_blend_bwd_uses_queue(const saga_model* m, int B) {
-    static const int want_xt = getenv("SAGA_GEMM_XT") ? atoi(getenv("SAGA_GEMM_XT")) : 3;
+    static const int want_xt = getenv("SAGA_GEMM_XT") ? atoi(getenv("SAGA_GEMM_XT")) : 1;
     static const int want_bwd = getenv("SAGA_GEMM_XT_BWD") ? atoi(getenv("SAGA_GEMM_XT_BWD")) : 1;
     static const int want_xcd = getenv("SAGA_GEMM_XCD") ? atoi(getenv("SAGA_GEMM_XCD")) : 1;
     if (want_xt <= 0 || !want_bwd || !want_xcd || B <= 0 || B % BM != 0) return false;

@@ -197,9 +197,9 @@ def test_overlapped_tile_backward_equals_one_tile_launches_bit_for_bit(body_mode
 @pytest.mark.parametrize('B', [512, 1024, 2048])
 def test_overlapped_tile_forward_with_one_or_two_tiles_per_block(body_model_dir, B):
     """The persistent kernel's short walks -- blocks whose first tile is their last (no stores to interleave, nothing to
-    prefetch), blocks with two tiles (the first interleaved stores follow a tile that had none) -- only occur below the
-    batch sizes it is used for by default: SAGA_GEMM_XT=1 (read once per process, hence a child process) takes it from one
-    tile per block on.  B = 512: 984 tiles for 512 blocks, B = 1,024: 1,968 -- and the backward with exactly one tile per block
+    prefetch), blocks with two tiles (the first interleaved stores follow a tile that had none).  In a child process with
+    SAGA_GEMM_XT=1 spelled out (the switch is read once per process; 1 is also the default since the kernels were measured
+    to win from one tile per block on).  B = 512: 984 tiles for 512 blocks, B = 1,024: 1,968 -- and the backward with exactly one tile per block
     (B = 1,024: 512 tiles) and two (B = 2,048)."""
     import os
     import subprocess
