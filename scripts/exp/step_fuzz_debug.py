@@ -28,7 +28,13 @@ loss_n, mk_n = op_n.native_step(stage, prob, terms)
 loss_a, ld, mk_a, *_ = op_a.calc_loss_contact_map(cu(d['markers']), cu(d['verts_o']), cu(d['normals_o']), cu(d['oc']), cu(d['mc']),
                                                   'male', None, stage, 1.0)
 dm = (mk_n - mk_a).abs().amax(dim=(1, 2)).cpu().numpy()
-print('marker diff per candidate (max):', np.round(dm, 7).tolist())
+print('marker diff per candidate: max %.3e at candidate %d; median %.3e' % (dm.max(), int(dm.argmax()), float(np.median(dm))))
+w = int(dm.argmax())
+with torch.no_grad():
+    bp = op_a.body_params()
+    for k in ('global_orient', 'body_pose'):
+        a = bp[k].detach().reshape(B, -1, 3)[w].norm(dim=-1).cpu().numpy()
+        print('  worst candidate', k, 'joint angles (rad): max %.4f' % a.max(), 'pi - max = %.2e' % (np.pi - a.max()))
 bp_n = op_n.body_params()
 with torch.no_grad():
     bp_a = op_a.body_params()
