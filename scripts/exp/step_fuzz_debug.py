@@ -48,3 +48,18 @@ for i, k in enumerate(loss_ref.LOSS_KEYS):
     rel = np.abs(t_[:, i] - a) / np.maximum(np.abs(a), 1e-7)
     if rel.max() > 1e-4:
         print('term', k, 'rows', np.nonzero(rel > 1e-4)[0].tolist(), 'native', t_[rel > 1e-4, i], 'autograd', a[rel > 1e-4])
+
+# both paths' markers against the float64 oracle on the same variables: which one carries the difference?
+from tests.helpers import load_oracle_model  # noqa: E402
+bm64 = load_oracle_model(tmp.name, B, dtype=torch.float64)
+var = {k: torch.from_numpy(v).double() for k, v in var_np.items()}
+t64 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).double()
+with torch.no_grad():
+    total, ld64, cnt, aux = loss_ref.loss_batched(bm64, var, vp.weights_dict(torch.float64), idx, t64(d['markers']), t64(d['verts_o']),
+                                                  t64(d['normals_o']), t64(d['oc']), t64(d['mc']), stage, only_rec=only_rec,
+                                                  contact_loss=contact_loss)
+ref = aux['markers_rec'].numpy()
+dn = np.abs(mk_n.detach().cpu().numpy() - ref).max(axis=(1, 2))
+da = np.abs(mk_a.detach().cpu().numpy() - ref).max(axis=(1, 2))
+print('against the float64 oracle: native max %.3e (candidate %d), autograd composition max %.3e (candidate %d); at the worst candidate of the pair: native %.3e autograd %.3e'
+      % (dn.max(), int(dn.argmax()), da.max(), int(da.argmax()), dn[w], da[w]))

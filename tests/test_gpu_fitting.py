@@ -837,8 +837,8 @@ def _step_fuzz_case(body_model_dir, B, O, stage, objective, seed):
         assert (err > LOSS_RTOL).sum() <= max(3, int(0.1 * B)), (name, tag, np.nonzero(err > LOSS_RTOL)[0].tolist(), float(err.max()))
 
     close(loss_n.cpu().numpy(), loss_a.detach().cpu().numpy(), 'objective')
-    # (markers: median difference 1.4e-6 m; a candidate whose decoded pose has a joint angle within 0.2 rad of pi reached 1.2e-4 --
-    # the axis-angle form both paths pass through amplifies the decoders' rounding difference there)
+    # (markers: median difference 1.4e-6 m; one candidate in 400 reached 1.2e-4 -- an ill-conditioned decoded joint rotation, where
+    # BOTH float32 paths are 0.7e-4 / 1.9e-4 m from the float64 oracle on the same variables: scripts/exp/step_fuzz_debug.py)
     assert (mk_n - mk_a).abs().max() < 5e-4, (tag, float((mk_n - mk_a).abs().max()))
     t = terms.cpu().numpy()
     for i, k in enumerate(loss_ref.LOSS_KEYS):
