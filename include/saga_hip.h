@@ -87,7 +87,8 @@ int  saga_model_weight_nnz(const saga_model_t* m);
  *   shape      [B,S]     betas ++ expression
  *   full_pose  [B,165]   axis-angle, pose_mean already added
  *   transl     [B,3] or NULL
- *   vertices   [B,V,3]   out
+ *   vertices   [B,V,3]   out (its first 32 bytes also serve as the tile counters of the persistent blend kernel while the call
+ *                        runs, before the skinning kernel writes the rows: output memory only, nothing for the caller to do)
  *   joints     [B,55+E+L,3] out
  * saved for backward (all out, caller-allocated):
  *   feat    [B,512]      [shape | vec(R_j - I), j=1..54 | 0]
@@ -112,7 +113,8 @@ int saga_smplx_fwd_selected(const saga_model_t* m, const saga_model_t* sub, cons
 
 /* SMPL-X backward (what loss.backward() drives through smplx at fittingop.py:383).
  *   g_vertices [B,V,3] or NULL; g_joints [B,55+E+L,3] or NULL (at least one non-NULL)
- *   g_shape [B,S], g_full_pose [B,165], g_transl [B,3] : out
+ *   g_shape [B,S], g_full_pose [B,165], g_transl [B,3] : out (the first 32 bytes of g_full_pose serve as the tile counters of the
+ *                        persistent split-K kernel in between, as `vertices` does in the forward)
  * workspace (caller-allocated, contents undefined on entry):
  *   ws_gvp   [B,Npad]                 grad wrt v_posed
  *   ws_slab  [SAGA_BWD_SPLITK,B,512]  split-K partials of grad wrt feat (before that: partial sums of ws_dA)
